@@ -1,0 +1,123 @@
+"""Loader / builder of the C-ABI shared library (include/fr_hotpath.h) and thin ctypes call helpers.
+
+There is deliberately NO fallback: if libfr_hotpath.so cannot be built or loaded, or a tensor is not on a GPU,
+the hot path raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG_DIR, "csrc")
+LIB_PATH = os.path.join(_PKG_DIR, "libfr_hotpath.so")
+SOURCES = ["fr_capi.hip", "fr_render.hip", "fr_decode.hip"]
+HEADERS = [os.path.join(_CSRC, "fr_common.h"), os.path.join(_PKG_DIR, "..", "include", "fr_hotpath.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+FR_OK = 0
+_ERR_NAMES = {-1: "invalid argument", -2: "workspace / packed buffer too small", -3: "HIP launch or runtime error",
+              -4: "size not supported by the gfx950 kernels"}
+
+_lock = threading.Lock()
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(_CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def compile(force=False, verbose=False):
+    """Cross-compiles the HIP kernels + C ABI for gfx950 with hipcc (works without a GPU)."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(_CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=_CSRC)
+    return LIB_PATH
+
+
+def _bind(L):
+    L.fr_version.restype = ctypes.c_char_p
+    L.fr_strerror.argtypes = [_i]
+    L.fr_strerror.restype = ctypes.c_char_p
+    L.fr_render_depth_workspace_bytes.argtypes = [_i] * 5
+    L.fr_render_depth_workspace_bytes.restype = ctypes.c_size_t
+    L.fr_render_depth_forward.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                                          ctypes.c_size_t, _vp]
+    L.fr_render_depth_forward.restype = _i
+    L.fr_render_depth_backward.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    L.fr_render_depth_backward.restype = _i
+    L.fr_decode_packed_basis_bytes.argtypes = [_i, _i, _i]
+    L.fr_decode_packed_basis_bytes.restype = ctypes.c_size_t
+    L.fr_decode_pack_basis.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
+    L.fr_decode_pack_basis.restype = _i
+    L.fr_decode_3dmm.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp]
+    L.fr_decode_3dmm.restype = _i
+    return L
+
+
+EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_render_depth_forward",
+           "fr_render_depth_backward", "fr_decode_packed_basis_bytes", "fr_decode_pack_basis", "fr_decode_3dmm"]
+
+
+def lib():
+    """Returns the bound ctypes library, building it first if the .so is missing (the reference's
+    build-on-import fallback, rendering_layer/ops.py:63-72).  Raises if it can be neither built nor loaded."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                import torch  # noqa: F401  (loads the ROCm runtime this library binds to, by SONAME)
+                if not os.path.exists(LIB_PATH):
+                    compile()
+                try:
+                    _lib = _bind(ctypes.CDLL(LIB_PATH))
+                except OSError as e:
+                    raise RuntimeError("fr_hotpath: cannot load %s (%s); run compile() -- there is no CPU fallback"
+                                       % (LIB_PATH, e))
+    return _lib
+
+
+def check(rc, what):
+    if rc != FR_OK:
+        msg = _ERR_NAMES.get(rc, "unknown error %d" % rc)
+        if rc == -1:
+            raise ValueError("%s: %s" % (what, msg))
+        raise RuntimeError("%s: %s" % (what, msg))
+
+
+def require_gpu_f32(t, name):
+    import torch
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s is on %s: the fr_hotpath kernels run on an MI355X only (no CPU fallback)"
+                           % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    return t.contiguous()
+
+
+def stream_ptr(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None

@@ -1,0 +1,75 @@
+// extern "C" entry points declared in include/fr_hotpath.h: argument validation (the OP_REQUIRES checks of
+// render_depth_op.cc:408-418, 498-503 re-stated) and dispatch to the gfx950 launchers.
+#include "fr_common.h"
+
+extern "C" {
+
+const char* fr_version(void) { return "fr_hotpath 0.1 (gfx950)"; }
+
+const char* fr_strerror(int code) {
+    switch (code) {
+        case FR_OK: return "ok";
+        case FR_ERR_INVALID_ARG: return "invalid argument";
+        case FR_ERR_WORKSPACE: return "workspace / packed buffer too small";
+        case FR_ERR_LAUNCH: return "HIP launch or runtime error";
+        case FR_ERR_UNSUPPORTED: return "size not supported by the gfx950 kernels";
+        default: return "unknown error";
+    }
+}
+
+size_t fr_render_depth_workspace_bytes(int B, int nver, int ntri, int H, int W) {
+    (void)B; (void)nver; (void)ntri; (void)H; (void)W;
+    return 0;  // the strip rasteriser keeps its bins in LDS
+}
+
+int fr_render_depth_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
+                            int H, int W, int C, int tex_batch, float* depth, float* tex_img, float* normal,
+                            float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream) {
+    if (B < 0 || nver < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
+    if (C != 3) return FR_ERR_INVALID_ARG;                         // render_depth_op.cc:418
+    if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
+    if (ws_bytes < fr_render_depth_workspace_bytes(B, nver, ntri, H, W)) return FR_ERR_WORKSPACE;
+    if ((size_t)B * H * W == 0) return FR_OK;                      // empty batch / image: nothing to write
+    if (!depth || !tex_img || !normal || !tri_ind) return FR_ERR_INVALID_ARG;
+    if (ntri > 0 && (!tri || (nver > 0 && (!vertex || !texture)))) return FR_ERR_INVALID_ARG;
+    if (ntri >= (1 << 24)) return FR_ERR_UNSUPPORTED;              // float-stored ids stop being exact
+    return fr_launch_render_forward(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal,
+                                    tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream);
+}
+
+int fr_render_depth_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
+                             int B, int nver, int ntri, int H, int W, void* hip_stream) {
+    if (B < 0 || nver < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
+    if ((size_t)B * nver == 0) return FR_OK;
+    if (!vertex_grad) return FR_ERR_INVALID_ARG;
+    if ((size_t)B * H * W > 0 && ntri > 0 && (!depth_grad || !tri || !tri_ind)) return FR_ERR_INVALID_ARG;
+    return fr_launch_render_backward(depth_grad, tri, tri_ind, vertex_grad, B, nver, ntri, H, W,
+                                     (hipStream_t)hip_stream);
+}
+
+size_t fr_decode_packed_basis_bytes(int N, int n_shape, int n_exp) {
+    if (N < 0 || n_shape < 0 || n_exp < 0) return 0;
+    return fr_packed_basis_bytes(N, n_shape, n_exp);
+}
+
+int fr_decode_pack_basis(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
+                         void* packed, size_t packed_bytes, void* hip_stream) {
+    if (N < 0 || n_shape < 0 || n_exp < 0) return FR_ERR_INVALID_ARG;
+    if (packed_bytes < fr_packed_basis_bytes(N, n_shape, n_exp)) return FR_ERR_WORKSPACE;
+    if (N == 0) return FR_OK;
+    if (!mu || !packed || (n_shape > 0 && !pc_shape) || (n_exp > 0 && !pc_exp)) return FR_ERR_INVALID_ARG;
+    if (((uintptr_t)packed & 15) != 0) return FR_ERR_INVALID_ARG;
+    return fr_launch_pack_basis(mu, pc_shape, pc_exp, N, n_shape, n_exp, packed, (hipStream_t)hip_stream);
+}
+
+int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R_override, int B, int N, int n_shape,
+                   int n_exp, float im_size, float* vertex_proj, void* hip_stream) {
+    if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0) return FR_ERR_INVALID_ARG;
+    if ((size_t)B * N == 0) return FR_OK;
+    if (!params || !packed_basis || !vertex_proj) return FR_ERR_INVALID_ARG;
+    if (((uintptr_t)packed_basis & 15) != 0) return FR_ERR_INVALID_ARG;
+    return fr_launch_decode(params, packed_basis, R_override, B, N, n_shape, n_exp, im_size, vertex_proj,
+                            (hipStream_t)hip_stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// Shared device helpers for the gfx950 hot-path kernels.  This TU set is compiled with -ffp-contract=off:
+// the reference CPU functor is built without FMA (g++ -O2 on baseline x86-64, rendering_layer/ops.py:51), so
+// every fp64/fp32 product and sum below must round individually; fused operations appear only where written
+// explicitly (__builtin_fmaf, MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "../../include/fr_hotpath.h"
+
+namespace fr {
+
+// (float)(-99999999999999) == -100000000376832.0f  (render_depth_op.cc:186)
+__device__ __forceinline__ float bg_depth() { return -99999999999999.0f; }
+
+// x86 cvttss2si semantics of the reference's (int) casts: NaN / out-of-range -> INT_MIN.
+__device__ __forceinline__ int f2i_x86(float f) {
+    return (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : INT_MIN;
+}
+
+// render_depth_op.h:15-16 min/max macros (NaN-sensitive ordering of the comparisons matters).
+__device__ __forceinline__ float mn(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float mx(float a, float b) { return a > b ? a : b; }
+
+// Monotone map fp32 -> u32 (a < b  <=>  ord(a) < ord(b) for non-NaN a, b with -0 canonicalised to +0).
+__device__ __forceinline__ uint32_t f32_ord(float h) {
+    uint32_t u = __float_as_uint(h);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unord(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+
+// Packed per-pixel key: max over keys == "largest h wins, ties -> lowest triangle index" (the serial
+// semantics of render_depth_op.cc:263-316 with its strict '<' at :295).
+__device__ __forceinline__ unsigned long long make_key(float h, int t) {
+    return ((unsigned long long)f32_ord(h) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)t);
+}
+__device__ __forceinline__ unsigned long long bg_key() {
+    return ((unsigned long long)f32_ord(bg_depth()) << 32) | 0xFFFFFFFFull;
+}
+
+// Barycentric inside test, op flavour (u+v < 1), fp64, operation order of render_depth_op.cc:90-121.
+struct TriSetup {
+    double x1, y1;
+    double v0x, v0y, v1x, v1y;
+    double dot00, dot01, dot11, inv;
+};
+__device__ __forceinline__ TriSetup tri_setup(float fx1, float fy1, float fx2, float fy2, float fx3, float fy3) {
+    TriSetup s;
+    s.x1 = (double)fx1;
+    s.y1 = (double)fy1;
+    s.v0x = (double)fx3 - s.x1;
+    s.v0y = (double)fy3 - s.y1;
+    s.v1x = (double)fx2 - s.x1;
+    s.v1y = (double)fy2 - s.y1;
+    s.dot00 = s.v0x * s.v0x + s.v0y * s.v0y;
+    s.dot01 = s.v0x * s.v1x + s.v0y * s.v1y;
+    s.dot11 = s.v1x * s.v1x + s.v1y * s.v1y;
+    double den = s.dot00 * s.dot11 - s.dot01 * s.dot01;
+    s.inv = (den == 0) ? 0.0 : 1 / den;
+    return s;
+}
+__device__ __forceinline__ bool point_in_tri(const TriSetup& s, int x, int y) {
+    double v2x = (double)x - s.x1;
+    double v2y = (double)y - s.y1;
+    double dot02 = s.v0x * v2x + s.v0y * v2y;
+    double dot12 = s.v1x * v2x + s.v1y * v2y;
+    double u = (s.dot11 * dot02 - s.dot01 * dot12) * s.inv;
+    if (u < 0 || u > 1) return false;
+    double v = (s.dot00 * dot12 - s.dot01 * dot02) * s.inv;
+    if (v < 0 || v > 1) return false;
+    return u + v < 1;
+}
+
+}  // namespace fr
+
+// Raise a kernel's dynamic-LDS limit to the CU's full 160 KiB, once per (kernel, device): not a stream operation, so
+// it is kept out of the steady-state launch path (and out of hipGraph captures).
+inline hipError_t fr_allow_full_lds(const void* kernel, unsigned char* done /*[64], zero-initialised*/) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = 1;
+    return e;
+}
+
+// host-side launchers implemented in the .hip files
+int fr_launch_render_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
+                             int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
+                             float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream);
+int fr_launch_render_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
+                              int B, int nver, int ntri, int H, int W, hipStream_t stream);
+size_t fr_packed_basis_bytes(int N, int n_shape, int n_exp);
+int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
+                         void* packed, hipStream_t stream);
+int fr_launch_decode(const float* params, const void* packed, const float* R_override, int B, int N, int n_shape,
+                     int n_exp, float im_size, float* vertex_proj, hipStream_t stream);

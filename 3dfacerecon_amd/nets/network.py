@@ -1,0 +1,184 @@
+"""Hot-path half of the reference's nets/network.py `FaceRecNet`, on PyTorch-ROCm + the gfx950 C ABI.
+
+Only the 3DMM decoder and the rendering-layer wrapper are here -- the methods on the CoarseNet -> render loop
+that BASELINE.json's north_star names:
+
+    vertices_transform(pred_params)            reference nets/network.py:140-171   (HIP: fr_decode_3dmm)
+    rendering_layer(vertex_proj, tri, colors)  reference nets/network.py:174-201   (HIP: fr_render_depth_forward)
+    set_constraints / parse_pose_params / rotation_matrix / rotation_matrix_batch  (:204-218, :253-297)
+
+CoarseNet / FineNet / losses / summaries / checkpoints (network.py:103-136, 311-603) are out of scope.
+The 235-d layout is unchanged: [phi, gamma, theta, tx, ty, tz, f | shape x199 | exp x29].
+"""
+import importlib.util
+import os
+import sys
+from math import cos, sin
+
+import numpy as np
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name, relpath):
+    mod = sys.modules.get(name)
+    if mod is None:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(_PKG_DIR, relpath))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    return mod
+
+
+def _host():
+    return _load("_fr_hotpath_host", "_lib.py")
+
+
+def _ops():
+    return _load("_fr_hotpath_ops", os.path.join("rendering_layer", "ops.py"))
+
+
+class FaceRecNet:
+    def __init__(self, im_gray=None, params_label=None, mesh_data=None, nIter=4, batch_size=64, im_size=200,
+                 weight_decay=1e-4, device="cuda"):
+        self.im_gray = im_gray
+        self.params_label = params_label
+        self.nIter = nIter
+        self.batch_size = batch_size
+        self.im_size = im_size
+        self.weight_decay = weight_decay
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("FaceRecNet hot path needs an MI355X device (got %s); there is no CPU fallback"
+                               % self.device)
+
+        # mesh data (same dict keys as utils/parser_3dmm.py:50-60)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.vertex_code = torch.as_tensor(np.asarray(mesh_data['vertex'], np.float32), **f32)    # (3, N)
+        self.tri = torch.as_tensor(np.asarray(mesh_data['tri'], np.float32), **f32)               # (3, T) float ids
+        self.mu = torch.as_tensor(np.asarray(mesh_data['mu'], np.float32).reshape(-1), **f32)      # (3*N,)
+        self.pc_shape = torch.as_tensor(np.asarray(mesh_data['pc_shape'], np.float32), **f32)     # (3*N, ndim_shape)
+        self.pc_exp = torch.as_tensor(np.asarray(mesh_data['pc_exp'], np.float32), **f32)         # (3*N, ndim_exp)
+
+        # mesh info
+        self.ndim_shape = int(mesh_data['ndim_shape'])
+        self.ndim_exp = int(mesh_data['ndim_exp'])
+        self.ndim_pose = int(mesh_data['ndim_pose'])
+        self.ndim = self.ndim_pose + self.ndim_shape + self.ndim_exp
+        self.nvert = int(self.mu.numel() // 3)
+        if self.ndim_pose != 7:
+            raise ValueError("ndim_pose must be 7")
+        if tuple(self.pc_shape.shape) != (3 * self.nvert, self.ndim_shape) or \
+                tuple(self.pc_exp.shape) != (3 * self.nvert, self.ndim_exp):
+            raise ValueError("pc_shape / pc_exp must be (3*Nvert, ndim)")
+
+        # one-time re-layout of the constant basis into MFMA-fragment order (include/fr_hotpath.h)
+        h = _host()
+        L = h.lib()
+        nbytes = L.fr_decode_packed_basis_bytes(self.nvert, self.ndim_shape, self.ndim_exp)
+        self._packed = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.fr_decode_pack_basis(h.ptr(self.mu), h.ptr(self.pc_shape), h.ptr(self.pc_exp), self.nvert,
+                                        self.ndim_shape, self.ndim_exp, h.ptr(self._packed), nbytes,
+                                        h.stream_ptr(self.device))
+        h.check(rc, "fr_decode_pack_basis")
+
+        # initial parameters (network.py:57-62)
+        geo = torch.zeros((batch_size, self.ndim_shape + self.ndim_exp), **f32)
+        init_pose = torch.tensor([0, 0, 0, im_size / 2.0, im_size / 2.0, 0, 0.001], **f32)
+        self.pred_params = torch.cat([init_pose[None].repeat(batch_size, 1), geo], 1)[:, None, None, :]  # (B,1,1,d)
+
+    # ---- 3DMM decode ----------------------------------------------------------------------------------
+    def vertices_transform(self, pred_params, R=None):
+        """(B,1,1,d) or (B,d) parameters -> projected vertices (B,3,N)  (network.py:140-171).
+
+        R: optional host-computed (B,3,3) rotation (what the reference gets from tf.py_func at :150); by default
+        the rotation is evaluated inside the kernel in float64."""
+        h = _host()
+        p = pred_params
+        if p.dim() == 4:
+            p = p.reshape(p.shape[0], p.shape[-1])
+        if p.dim() != 2 or p.shape[1] != self.ndim:
+            raise ValueError("pred_params must be (B,1,1,%d) or (B,%d)" % (self.ndim, self.ndim))
+        p = h.require_gpu_f32(p, "pred_params")
+        B = int(p.shape[0])
+        Rc = None
+        if R is not None:
+            Rc = h.require_gpu_f32(torch.as_tensor(R, dtype=torch.float32, device=p.device), "R")
+            if tuple(Rc.shape) != (B, 3, 3):
+                raise ValueError("R must be (B,3,3)")
+        out = torch.empty((B, 3, self.nvert), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            rc = h.lib().fr_decode_3dmm(h.ptr(p), h.ptr(self._packed), h.ptr(Rc), B, self.nvert, self.ndim_shape,
+                                        self.ndim_exp, float(self.im_size), h.ptr(out), h.stream_ptr(p.device))
+        h.check(rc, "fr_decode_3dmm")
+        return out
+
+    # ---- rendering layer wrapper --------------------------------------------------------------------------
+    def rendering_layer(self, vertex_proj, triangles, colors, im_gray=None):
+        """(network.py:174-201) -> pncc_batch, normalimg_batch, maskimg_batch, depthimg_batch."""
+        im_gray = self.im_gray if im_gray is None else im_gray
+        ver = vertex_proj.float()
+        tri = torch.as_tensor(triangles, dtype=torch.float32, device=ver.device)
+        tex = torch.as_tensor(colors, dtype=torch.float32, device=ver.device)  # (3,N) shared across the batch
+        B = ver.shape[0]
+        if im_gray is None:
+            im_gray = torch.ones((B, self.im_size, self.im_size, 1), dtype=torch.float32, device=ver.device)
+        image = im_gray.expand(-1, -1, -1, 3)
+        depth, tex_img, normal, _ = _ops().render_depth(ver=ver, tri=tri, texture=tex, image=image)
+        # 1. pncc result
+        pncc_batch = torch.clamp(tex_img, 1e-6, 1.0)
+        # 2. normal map: flip normals with negative z, normalise by magnitude
+        flip = normal[..., 2:3] < 0
+        normal = torch.where(flip, -1.0 * normal, normal)
+        mag = (normal * normal).sum(-1)
+        mag = torch.where(mag > 1e-6, mag, torch.ones_like(mag))
+        normalimg_batch = normal / (torch.sqrt(mag) + 1e-6)[..., None]
+        # 3. masked image
+        mask = torch.clamp(depth, 1e-6, 1.0)
+        maskimg_batch = mask * im_gray
+        # 4. depth image
+        depthimg_batch = torch.clamp_min(depth, 1e-6)
+        return pncc_batch, normalimg_batch, maskimg_batch, depthimg_batch
+
+    def depth_rendering_layer(self):
+        """(network.py:300-309)"""
+        self.vertices_proj = self.vertices_transform(self.pred_params)
+        self.pncc_batch, self.normal_batch, self.maskimg_batch, self.coarse_depth_map = \
+            self.rendering_layer(self.vertices_proj, self.tri, self.vertex_code)
+        return self.coarse_depth_map
+
+    # ---- parameter helpers ----------------------------------------------------------------------------------
+    def set_constraints(self, pred_params):
+        """sigmoid -> value ranges of the 235-d vector (network.py:204-218)."""
+        s = torch.sigmoid(pred_params)
+        nps, ns = self.ndim_pose, self.ndim_shape
+        self.pred_params = torch.cat([s[..., 0:3] * 3.0 - 1.5,
+                                      s[..., 3:5] * self.im_size,
+                                      s[..., 5:6] * 0.0,
+                                      s[..., 6:7] * 1e-3,
+                                      s[..., nps:nps + ns] * 1e4,
+                                      s[..., nps + ns:self.ndim] * 3.0 - 1.5], dim=-1)
+        return self.pred_params
+
+    def parse_pose_params(self, pose_params):
+        """(B,7) -> phi, gamma, theta (B,1), t3d (B,3), f (B,1)  (network.py:253-263)."""
+        return (pose_params[:, 0:1], pose_params[:, 1:2], pose_params[:, 2:3], pose_params[:, 3:6],
+                pose_params[:, 6:7])
+
+    def rotation_matrix(self, angles):
+        """Host numpy rotation, float64 trig and products, one rounding to fp32 (network.py:266-291)."""
+        phi, gamma, theta = angles
+        R_pitch = np.array([[1, 0, 0], [0, cos(phi), sin(phi)], [0, -sin(phi), cos(phi)]])
+        R_yaw = np.array([[cos(gamma), 0, -sin(gamma)], [0, 1, 0], [sin(gamma), 0, cos(gamma)]])
+        R_roll = np.array([[cos(theta), sin(theta), 0], [-sin(theta), cos(theta), 0], [0, 0, 1]])
+        return np.dot(np.dot(R_pitch, R_yaw), R_roll).astype(np.float32)
+
+    def rotation_matrix_batch(self, angles_batch):
+        """(network.py:292-297)"""
+        angles_batch = np.asarray(angles_batch)
+        R_batch = np.zeros([angles_batch.shape[0], 3, 3], dtype=np.float32)
+        for i in range(angles_batch.shape[0]):
+            R_batch[i] = self.rotation_matrix(angles_batch[i])
+        return R_batch

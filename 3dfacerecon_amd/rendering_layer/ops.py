@@ -1,0 +1,156 @@
+"""Operator surface of the rendering layer -- the MI355X drop-in for the reference's rendering_layer/ops.py.
+
+Same names and argument meaning as the reference module (rendering_layer/ops.py:12,23,78-95):
+
+    OP_NAMES                       ['render_depth']
+    compile(op=None)               build the native library (hipcc --offload-arch=gfx950, not nvcc + g++)
+    render_depth(ver, tri, texture, image, **kwargs)
+                                   -> (depth [B,H,W,1], texture_image [B,H,W,3], normal [B,H,W,3], tri_ind [B,H,W,1])
+    gradient                       flows to `ver` only (d depth / d vertex z); tri, texture, image get None
+
+Tensors are torch.Tensors on an MI355X instead of tf.Tensors; the op is a torch.autograd.Function calling the
+C ABI of include/fr_hotpath.h through ctypes on torch's current HIP stream.  Like the reference, importing the
+module loads the native library and builds it first if the .so is missing (reference ops.py:63-72) -- but there
+is no fallback path: no library or no GPU tensor => an exception.
+"""
+import importlib.util
+import os
+import sys
+
+import torch
+
+# Register ops for compilation here (reference ops.py:12)
+OP_NAMES = ['render_depth']
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _host():
+    """The ctypes host module (3dfacerecon_amd/_lib.py), loaded by path so that this file works both as
+    `3dfacerecon_amd.rendering_layer.ops` and as the reference-style top-level `rendering_layer.ops`."""
+    name = "_fr_hotpath_host"
+    mod = sys.modules.get(name)
+    if mod is None:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(_PKG_DIR, "_lib.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    return mod
+
+
+def compile(op=None):
+    """Build the native op library.  `op` is accepted for signature compatibility (reference ops.py:23-27);
+    all ops of OP_NAMES live in one shared library."""
+    if op is not None and op not in OP_NAMES:
+        raise ValueError("unknown op %r (known: %s)" % (op, OP_NAMES))
+    return _host().compile(force=True, verbose=True)
+
+
+# build-on-import fallback, then load (reference ops.py:63-72).  A missing hipcc or a failing build raises here.
+_host().lib()
+
+
+def _check_forward_shapes(ver, tri, texture, image):
+    # the OP_REQUIRES checks of RenderDepthOp::Compute (render_depth_op.cc:397-418), same messages
+    if image.dim() != 4 or ver.dim() != 3 or tri.dim() != 2 or texture.dim() not in (2, 3):
+        raise ValueError("render_depth expects ver [B,3,nver], tri [3,ntri], texture [B,3,nver], image [B,H,W,C]")
+    B = image.shape[0]
+    if ver.shape[0] != B:
+        raise ValueError("The vertex's batch is not the same as image batch")
+    if ver.shape[1] != 3:
+        raise ValueError("The vertex is not Batch x 3 x nver")
+    if tri.shape[0] != 3:
+        raise ValueError("The tri is not 3 x ntri")
+    if texture.shape[-2] != 3:
+        raise ValueError("The texture channel must be equal to image channel namely 3")
+    if texture.shape[-1] != ver.shape[2]:
+        raise ValueError("The texture is not Batch x 3 x nver")
+    if texture.dim() == 3 and texture.shape[0] not in (1, B):
+        raise ValueError("The texture's batch is neither 1 nor the image batch")
+
+
+class _RenderDepth(torch.autograd.Function):
+    """RenderDepth / RenderDepthGrad (render_depth_op.cc:535-589) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, ver, tri, texture, image):
+        h = _host()
+        _check_forward_shapes(ver, tri, texture, image)
+        ver_c = h.require_gpu_f32(ver, "ver")
+        tri_c = h.require_gpu_f32(tri, "tri")
+        tex_c = h.require_gpu_f32(texture, "texture")
+        if not image.is_cuda:
+            raise RuntimeError("image is on %s: the fr_hotpath kernels run on an MI355X only" % image.device)
+        B, H, W = int(image.shape[0]), int(image.shape[1]), int(image.shape[2])
+        nver, ntri = int(ver_c.shape[2]), int(tri_c.shape[1])
+        tex_batch = 1 if tex_c.dim() == 2 else int(tex_c.shape[0])
+        if tex_batch not in (1, B):
+            raise ValueError("The texture's batch is neither 1 nor the image batch")
+        dev = ver_c.device
+        opts = dict(dtype=torch.float32, device=dev)
+        depth = torch.empty((B, H, W, 1), **opts)
+        tex_img = torch.empty((B, H, W, 3), **opts)
+        normal = torch.empty((B, H, W, 3), **opts)
+        tri_ind = torch.empty((B, H, W, 1), **opts)
+        L = h.lib()
+        with torch.cuda.device(dev):
+            ws_bytes = L.fr_render_depth_workspace_bytes(B, nver, ntri, H, W)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+            rc = L.fr_render_depth_forward(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), B, nver, ntri, H, W, 3, tex_batch,
+                                           h.ptr(depth), h.ptr(tex_img), h.ptr(normal), h.ptr(tri_ind), h.ptr(ws),
+                                           ws_bytes, h.stream_ptr(dev))
+        h.check(rc, "fr_render_depth_forward")
+        ctx.save_for_backward(tri_c, tri_ind)
+        ctx.dims = (B, nver, ntri, H, W)
+        return depth, tex_img, normal, tri_ind
+
+    @staticmethod
+    def backward(ctx, depth_grad, texture_image_grad, normal_grad, tri_ind_grad):
+        # only depth_grad is used; vertex has gradients, tri / texture / image do not (reference ops.py:86-95)
+        h = _host()
+        tri_c, tri_ind = ctx.saved_tensors
+        B, nver, ntri, H, W = ctx.dims
+        dev = tri_c.device
+        vertex_grad = torch.empty((B, 3, nver), dtype=torch.float32, device=dev)
+        if depth_grad is None:
+            return vertex_grad.zero_(), None, None, None
+        g = h.require_gpu_f32(depth_grad, "depth_grad")
+        with torch.cuda.device(dev):
+            rc = h.lib().fr_render_depth_backward(h.ptr(g), h.ptr(tri_c), h.ptr(tri_ind), h.ptr(vertex_grad), B, nver,
+                                                  ntri, H, W, h.stream_ptr(dev))
+        h.check(rc, "fr_render_depth_backward")
+        return vertex_grad, None, None, None
+
+
+def render_depth(ver, tri, texture, image, **kwargs):
+    """Forward function of RenderDepth (reference ops.py:78-81).
+
+    The first output is the rendered depth, the fourth the triangle index each depth pixel corresponds to.
+    `image` only donates the batch / height / width (its values are never read, render_depth_op.cc:397-403).
+    `**kwargs` is accepted for call compatibility (TF passed `name=`); unknown keys are ignored.
+    """
+    return _RenderDepth.apply(ver, tri, texture, image)
+
+
+def render_depth_grad(depth_grad, ver, tri, depth, tri_ind, image):
+    """The RenderDepthGrad op called directly with the reference's argument order
+    (depth_grad, vertex, tri, depth, tri_ind, image; render_depth_op.cc:473-478) -> vertex_grad [B,3,nver]."""
+    h = _host()
+    g = h.require_gpu_f32(depth_grad, "depth_grad")
+    tri_c = h.require_gpu_f32(tri, "tri")
+    ti = h.require_gpu_f32(tri_ind, "tri_ind")
+    if ver.dim() != 3 or ver.shape[1] != 3:
+        raise ValueError("The vertex is not Batch x 3 x nver")
+    if ver.shape[0] != image.shape[0]:
+        raise ValueError("The vertex's batch is not the same as image batch")
+    if tri_c.dim() != 2 or tri_c.shape[0] != 3:
+        raise ValueError("The tri is not 3 x ntri")
+    B, H, W = int(image.shape[0]), int(image.shape[1]), int(image.shape[2])
+    nver, ntri = int(ver.shape[2]), int(tri_c.shape[1])
+    dev = g.device
+    vertex_grad = torch.empty((B, 3, nver), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = h.lib().fr_render_depth_backward(h.ptr(g), h.ptr(tri_c), h.ptr(ti), h.ptr(vertex_grad), B, nver, ntri, H, W,
+                                              h.stream_ptr(dev))
+    h.check(rc, "fr_render_depth_backward")
+    return vertex_grad

@@ -1,0 +1,68 @@
+"""One process per GPU under torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" for the CPU tests).
+
+The decode + render path is embarrassingly parallel over the batch (reference batch loop render_depth_op.cc:180;
+per-row decode network.py:153-169): faces are sharded across ranks and NO collective is on the data path.  The
+only collectives here are the bench's barrier and the max-over-ranks of the step time.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_from_env(backend=None):
+    """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1.
+    Returns (world, rank, local_rank)."""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return world, rank, local
+
+
+def shard_range(total, rank, world):
+    """Contiguous shard [lo, hi) of `total` faces for `rank`; sizes differ by at most one, earlier ranks get
+    the remainder, every face is owned exactly once."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    q, r = divmod(int(total), world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    """MAX of a python float over all ranks (the bench's step time)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device="cpu"):
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def finalize():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

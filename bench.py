@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline bench: faces/sec of 3DMM decode + depth render, batch 64 @ 200x200, fp32 (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one 64-face batch of synthetic 235-d parameters already resident in
+HBM: fr_decode_3dmm -> fr_render_depth_forward (all four output planes), through the C ABI, on the BFM-scale
+synthetic assets of SURVEY.md 8(d) (N = 53,215, T = 105,840, 199 + 29 components).  Every rank runs its own 64
+faces (weak scaling; the path has no collective), the K steps are bracketed by barrier + synchronize, the MAX
+over ranks is taken and rank 0 prints ONE JSON line.
+
+The oracle (oracle/) is used only for the `cpu_baseline` leg: its single-thread decode + render of a bounded
+sample of the same workload, timed on the host cores of the same box.
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# SURVEY.md 8(d) algorithmic bytes / flops (N=53,215, T=105,840, K=228, H=W=200)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: exact-f32 MFMA == fp32 vector peak
+
+
+def algorithmic_bytes(N, T, K, H, W, B):
+    basis = 4.0 * 3 * N * (K + 1) / B
+    params = 4.0 * (7 + K)
+    vproj = 4.0 * 3 * N
+    shared = (4.0 * 3 * T + 4.0 * 3 * N) / B
+    planes = 4.0 * H * W * 8
+    return {"pipeline": basis + params + 2 * vproj + shared + planes,
+            "render": vproj + shared + planes,
+            "decode": basis + params + vproj}
+
+
+def pkg(name):
+    return importlib.import_module("3dfacerecon_amd." + name)
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (nothing
+    here has touched the GPU yet) and exit with its code."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def cpu_baseline(assets, params_np, n_faces, H, W):
+    """Single-thread CPU restatement of the reference path on the first n_faces of the batch."""
+    import numpy as np
+    from oracle import oracle as O
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+    except (AttributeError, OSError):
+        pass
+    P = params_np[:n_faces]
+    O.decode_3dmm(P[:1], assets["mu"], assets["pc_shape"], assets["pc_exp"], float(H))  # warm-up (page-in)
+    t0 = time.perf_counter()
+    V = O.decode_3dmm(P, assets["mu"], assets["pc_shape"], assets["pc_exp"], float(H))
+    t1 = time.perf_counter()
+    O.render_depth(V, assets["tri"], assets["vertex"][None], H, W)
+    t2 = time.perf_counter()
+    # the MEX z-buffer of prepare_data/ZBuffer (all double, column-major), one face per call
+    nz = min(n_faces, 16)
+    src = np.zeros((H, W, 3))
+    tz0 = time.perf_counter()
+    for b in range(nz):
+        O.zbuffer_mex(V[b].astype(np.float64), assets["tri"].astype(np.float64), assets["vertex"].astype(np.float64), src)
+    tz1 = time.perf_counter()
+    total = t2 - t0
+    return {
+        "value": n_faces / total, "unit": "faces/s", "cores": 1, "kind": "port",
+        "sample": "%d faces of the same batch: fr_oracle_decode_3dmm (network.py:140-171 restated) + "
+                  "fr_oracle_render_depth_forward (render_depth_op.cc:132-322 restated), one thread, %.1f s"
+                  % (n_faces, total),
+        "decode_ms_per_face": 1e3 * (t1 - t0) / n_faces,
+        "render_ms_per_face": 1e3 * (t2 - t1) / n_faces,
+        "zbuffer_mex_ms_per_face": 1e3 * (tz1 - tz0) / nz,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="faces per GPU per step")
+    ap.add_argument("--im-size", type=int, default=200)
+    ap.add_argument("--cpu-faces", type=int, default=64, help="faces in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--graph", action="store_true", help="also report hipGraph-replay throughput")
+    args = ap.parse_args()
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env == 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
+
+    import numpy as np
+    import torch
+    dist_u = pkg("utils.dist")
+    world, rank, local = dist_u.init_from_env("nccl" if args.gpus > 1 else None)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X; the hot path has no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    synth = pkg("utils.synth")
+    netm = pkg("nets.network")
+    pipe = pkg("pipeline")
+    B, H, W = args.batch, args.im_size, args.im_size
+    assets = synth.make_assets()
+    net = netm.FaceRecNet(mesh_data=assets, batch_size=B, im_size=H, device=dev)
+    params_np = synth.sample_params_batch(B, im_size=H, beta=0.7, seed=3456 + rank)
+    plan = pipe.DecodeRenderPlan(net, B, H, W)
+    plan.params.copy_(torch.as_tensor(params_np, device=dev))
+    torch.cuda.synchronize(dev)
+
+    K, Wm = args.steps, args.warmup
+    for _ in range(Wm):
+        plan.step()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    dist_u.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(K):
+        ev[k][0].record()
+        plan.decode()
+        ev[k][1].record()
+        plan.render()
+        ev[k][2].record()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    dist_u.barrier()
+    elapsed = dist_u.max_over_ranks(t1 - t0, device=dev)
+    decode_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / K
+    render_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / K
+    cov = float((plan.tri_ind >= 0).float().mean().item())
+
+    graph_fps = None
+    if args.graph:
+        plan.capture()
+        for _ in range(Wm):
+            plan.replay()
+        torch.cuda.synchronize(dev)
+        g0 = time.perf_counter()
+        for _ in range(K):
+            plan.replay()
+        torch.cuda.synchronize(dev)
+        graph_fps = B * K / (time.perf_counter() - g0)
+
+    if rank == 0:
+        N, T, Kc = net.nvert, int(net.tri.shape[1]), net.ndim_shape + net.ndim_exp
+        ab = algorithmic_bytes(N, T, Kc, H, W, B)
+        value = world * B * K / elapsed
+        flops = 2.0 * 3 * N * Kc * B
+        roof_render = {"bound": "hbm", "kernel": "render_strip_kernel",
+                       "achieved": ab["render"] * B / (render_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "traffic": None, "avg_ms": render_ms}
+        roof_decode = {"bound": "mfma", "kernel": "decode_kernel",
+                       "achieved": flops / (decode_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "traffic": None, "avg_ms": decode_ms,
+                       "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9}
+        for r in (roof_render, roof_decode):
+            r["frac"] = r["achieved"] / r["peak"]
+        dominant = roof_render if render_ms >= decode_ms else roof_decode
+        out = {
+            "metric": "faces/sec (3DMM decode+depth render), batch 64 @200x200",
+            "value": value, "unit": "faces/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch %d random 235-d params -> 3DMM decode -> depth render, "
+                                   "%dx%d, fp32, all four output planes" % (B, H, W),
+                       "faces_per_gpu": B, "nver": N, "ntri": T, "n_shape": net.ndim_shape, "n_exp": net.ndim_exp,
+                       "sampler": "sample_test.py:23-38 beta=0.7 seed=3456+rank", "coverage": cov,
+                       "sharding": "batch over ranks, no data-path collective"},
+            "roofline": dominant,
+            "kernels": {"decode": roof_decode, "render": roof_render},
+            "pipeline_hbm": {"bytes_per_face": ab["pipeline"],
+                             "achieved_GBs": ab["pipeline"] * value / world / 1e9,
+                             "frac_of_8TBs": ab["pipeline"] * value / world / 1e9 / HBM_PEAK_GBS},
+        }
+        if graph_fps is not None:
+            out["graph_replay_faces_per_s"] = graph_fps
+        if args.cpu_faces > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(assets, params_np, min(args.cpu_faces, B), H, W)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    dist_u.barrier()
+    dist_u.finalize()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+/*
+ * fr_hotpath.h -- C ABI of the MI355X (gfx950) render_depth + 3DMM-decode hot path.
+ *
+ * This is the drop-in boundary.  The reference has no C ABI of its own for this path: its only native
+ * boundary is the TensorFlow OpKernel C++ ABI (rendering_layer/ops_src/render_depth_op.cc:371-604, loaded by
+ * rendering_layer/ops.py:68 through tf.load_op_library).  Each entry point below cites the reference
+ * interface it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds to rendering_layer/ops.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (outputs and workspace included); the library
+ *     allocates nothing and never synchronises with the host;
+ *   - `hip_stream` is a hipStream_t (NULL = the default stream); all work is enqueued on it, in order;
+ *   - return value: FR_OK (0) or a negative FR_ERR_* code (never swallowed, unlike the reference's
+ *     printf-and-return at render_depth_op.cu.cc:290-295); fr_strerror() names it;
+ *   - reentrant and thread-safe (no static scratch, unlike render_depth_op.cc:125-131).
+ *   - tensors are dense, row-major, fp32; triangle indices and tri_ind stay float-typed at the surface as in
+ *     the reference op schema (render_depth_op.cc:535-589).
+ */
+#ifndef FR_HOTPATH_H_
+#define FR_HOTPATH_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_OK 0
+#define FR_ERR_INVALID_ARG (-1) /* OP_REQUIRES failures, render_depth_op.cc:408-418, 498-503 */
+#define FR_ERR_WORKSPACE (-2)   /* workspace / packed-basis buffer too small */
+#define FR_ERR_LAUNCH (-3)      /* HIP launch or runtime error */
+#define FR_ERR_UNSUPPORTED (-4) /* size outside what the kernels cover (e.g. image row does not fit in LDS) */
+
+#define FR_N_POSE 7 /* [phi,gamma,theta,tx,ty,tz,f], reference README.md:43-46, utils/parser_3dmm.py:49 */
+
+/* Library identification / error text. */
+const char* fr_version(void);
+const char* fr_strerror(int code);
+
+/* ---- render_depth forward ------------------------------------------------------------------------------
+ * Replaces RenderDepthOp<Device>::Compute + functor RenderDepth (render_depth_op.cc:378-458, 132-322;
+ * CUDA launchers render_depth_op.cu.cc:239-341) reached from rendering_layer/ops.py:78-81.
+ *   vertex  [B,3,nver]  projected vertices (x = column, y = row, z = depth)
+ *   tri     [3,ntri]    float-stored 0-based vertex ids (truncated with (int), render_depth_op.cc:204-206)
+ *   texture [tex_batch,3,nver], tex_batch == B, or 1 to share one texture across the batch
+ *   depth [B,H,W,1], tex_img [B,H,W,3], normal [B,H,W,3], tri_ind [B,H,W,1]   (render_depth_op.cc:437-440)
+ * C must be 3 (render_depth_op.cc:418).  Semantics are those of the CPU functor: per pixel the triangle with
+ * the largest fp32 centroid depth wins, ties go to the lowest triangle index; background depth is
+ * (float)(-99999999999999), tri_ind -1, texture/normal 0.  Triangles with a vertex id outside [0,nver) are
+ * skipped.  `workspace` must hold fr_render_depth_workspace_bytes() bytes (may be NULL when that is 0). */
+size_t fr_render_depth_workspace_bytes(int B, int nver, int ntri, int H, int W);
+
+int fr_render_depth_forward(const float* vertex, const float* tri, const float* texture, int B, int nver,
+                            int ntri, int H, int W, int C, int tex_batch, float* depth, float* tex_img,
+                            float* normal, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream);
+
+/* ---- render_depth backward -----------------------------------------------------------------------------
+ * Replaces RenderDepthOpGrad::Compute + functor RenderDepthGrad (render_depth_op.cc:470-528, 325-368;
+ * render_depth_op.cu.cc:345-423) reached from the gradient registration at rendering_layer/ops.py:86-95.
+ *   depth_grad [B,H,W,1], tri [3,ntri], tri_ind [B,H,W,1] (forward output) -> vertex_grad [B,3,nver]
+ * vertex_grad is zero-filled, then every pixel with tri_ind >= 0 adds depth_grad/3 to the z row of its
+ * triangle's three vertices; x and y rows stay 0 (render_depth_op.cc:359-363). */
+int fr_render_depth_backward(const float* depth_grad, const float* tri, const float* tri_ind,
+                             float* vertex_grad, int B, int nver, int ntri, int H, int W, void* hip_stream);
+
+/* ---- 3DMM decode ---------------------------------------------------------------------------------------
+ * Replaces FaceRecNet.vertices_transform + parse_pose_params + rotation_matrix_batch
+ * (nets/network.py:140-171, 253-263, 266-297): 235-d parameters -> projected, y-flipped vertices [B,3,N].
+ *
+ * The basis is a constant of the model (tf.constant at network.py:41-43), so it is re-laid-out ONCE into an
+ * MFMA-fragment-ordered image in HBM by fr_decode_pack_basis and then streamed by every decode call:
+ *   mu [3N] (blocked: element r = coordinate r/N of vertex r%N, network.py:157),
+ *   pc_shape [3N,n_shape], pc_exp [3N,n_exp] row-major (network.py:42-43)
+ *   -> packed, fr_decode_packed_basis_bytes(N,n_shape,n_exp) bytes, 16-byte aligned. */
+size_t fr_decode_packed_basis_bytes(int N, int n_shape, int n_exp);
+
+int fr_decode_pack_basis(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape,
+                         int n_exp, void* packed, size_t packed_bytes, void* hip_stream);
+
+/*   params [B, 7+n_shape+n_exp] = [phi,gamma,theta,tx,ty,tz,f | alpha | beta]   (network.py:142-147)
+ *   R_override: NULL, or a caller-computed [B,3,3] rotation (what network.py:150 obtains through tf.py_func);
+ *               with NULL the rotation is evaluated in-kernel in float64 exactly as network.py:276-290 does.
+ *   vertex_proj [B,3,N]; y row is (im_size - y) - 1 (network.py:167-169).
+ * Numerical definition: include the S / E fmaf-chain spec of DESIGN.md "Decode numerics". */
+int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R_override, int B, int N,
+                   int n_shape, int n_exp, float im_size, float* vertex_proj, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FR_HOTPATH_H_ */

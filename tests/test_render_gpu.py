@@ -1,0 +1,201 @@
+"""GPU parity: fr_render_depth_forward (HIP, through rendering_layer/ops.py and the C ABI) vs the CPU oracle.
+Bar: bit-exact on all four planes (tri_ind / coverage are integers; depth, texture, normal are pure functions of
+the fp32 inputs under the reference's operation order)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, grid_from_rows, kat_inputs
+from gpu_util import assert_render_equal, render_gpu
+
+pytestmark = pytest.mark.gpu
+KAT = json.load(open(os.path.join(GOLDEN, "kat_survey.json")))
+
+
+@pytest.mark.parametrize("case", [c for c in KAT["cases"] if c["flavour"] == "op"], ids=lambda c: c["name"])
+def test_kat(oracle, case):
+    W, H = KAT["W"], KAT["H"]
+    ver, tri, tex = kat_inputs(case, W, H)
+    got = render_gpu(ver, tri, tex, H, W)
+    if "tri_ind" in case:
+        np.testing.assert_array_equal(got[3][0, :, :, 0], grid_from_rows(case["tri_ind"]))
+    assert_render_equal(got, oracle.render_depth(ver, tri, tex, H, W), case["name"])
+
+
+def test_golden_small(oracle, small_assets):
+    z = np.load(os.path.join(GOLDEN, "render_small_oracle.npz"))
+    got = render_gpu(z["vertex"], small_assets["tri"], small_assets["vertex"][None], int(z["H"]), int(z["W"]))
+    assert_render_equal(got, (z["depth"], z["texture_image"], z["normal"], z["tri_ind"]), "golden_small")
+
+
+def _random_scene(rs, B, nver, ntri, H, W, scale):
+    ver = np.empty((B, 3, nver), np.float32)
+    ver[:, 0] = rs.uniform(-0.1 * W, 1.1 * W, (B, nver))
+    ver[:, 1] = rs.uniform(-0.1 * H, 1.1 * H, (B, nver))
+    ver[:, 2] = rs.uniform(-50, 50, (B, nver))
+    # triangles: a base vertex plus two near-by ones so that sizes range from sub-pixel to tens of pixels
+    base = rs.randint(0, nver, ntri)
+    tri = np.stack([base, rs.randint(0, nver, ntri), rs.randint(0, nver, ntri)]).astype(np.float32)
+    # make most triangles small: overwrite vertices 2,3 positions relative to base for a subset
+    k = ntri // 2
+    idx = rs.permutation(nver)[: min(nver, 3 * k) // 3 * 3].reshape(-1, 3)
+    for b in range(B):
+        c = ver[b, :2, idx[:, 0]]
+        ver[b, :2, idx[:, 1]] = c + rs.uniform(-scale, scale, c.shape).astype(np.float32)
+        ver[b, :2, idx[:, 2]] = c + rs.uniform(-scale, scale, c.shape).astype(np.float32)
+    m = min(k, idx.shape[0])
+    tri[:, :m] = idx[:m].T
+    tex = rs.uniform(0, 1, (B, 3, nver)).astype(np.float32)
+    return ver, tri, tex
+
+
+@pytest.mark.parametrize("B,nver,ntri,H,W,scale", [
+    (1, 50, 80, 16, 16, 3.0),
+    (3, 300, 700, 33, 47, 2.0),     # odd sizes: scalar store path, ragged strips
+    (2, 1000, 3000, 64, 64, 1.0),
+    (5, 400, 900, 200, 200, 8.0),
+    (1, 200, 300, 7, 450, 5.0),     # wide image (448+ wide rows)
+    (4, 64, 40, 100, 3, 2.0),       # narrow image
+    (70, 120, 200, 24, 28, 2.5),    # more faces than one pass of bins per CU
+])
+def test_random_scenes(oracle, B, nver, ntri, H, W, scale):
+    rs = np.random.RandomState(B * 1000 + ntri)
+    ver, tri, tex = _random_scene(rs, B, nver, ntri, H, W, scale)
+    assert_render_equal(render_gpu(ver, tri, tex, H, W), oracle.render_depth(ver, tri, tex, H, W), "random")
+
+
+def test_shared_texture(oracle):
+    rs = np.random.RandomState(3)
+    ver, tri, tex = _random_scene(rs, 3, 100, 200, 20, 20, 3.0)
+    want = oracle.render_depth(ver, tri, tex[:1], 20, 20)
+    assert_render_equal(render_gpu(ver, tri, tex[:1], 20, 20), want, "tex_batch=1")
+    assert_render_equal(render_gpu(ver, tri, tex[0], 20, 20), want, "tex 2-D")
+
+
+def test_integer_coordinates_edge_rule(oracle):
+    # pixel centres exactly on edges / vertices / hypotenuse: pins u+v<1 and the inclusive u,v bounds
+    rs = np.random.RandomState(8)
+    nver, ntri, H, W = 60, 150, 12, 12
+    ver = np.empty((2, 3, nver), np.float32)
+    ver[:, 0] = rs.randint(0, W, (2, nver))
+    ver[:, 1] = rs.randint(0, H, (2, nver))
+    ver[:, 2] = rs.randint(0, 4, (2, nver))          # many equal h -> ties to the lowest index
+    tri = rs.randint(0, nver, (3, ntri)).astype(np.float32)
+    tex = rs.uniform(0, 1, (2, 3, nver)).astype(np.float32)
+    assert_render_equal(render_gpu(ver, tri, tex, H, W), oracle.render_depth(ver, tri, tex, H, W), "integer")
+
+
+def test_big_triangles_and_full_cover(oracle):
+    H, W = 40, 56
+    ver = np.array([[[0, W - 1, 0, W - 1, 10.5, 30.2, 20.1], [0, 0, H - 1, H - 1, 5.5, 9.1, 30.7],
+                     [1, 2, 3, 4, 9, 9, 9]]], np.float32)
+    tri = np.array([[0, 1, 2], [3, 2, 1], [4, 5, 6]], np.float32).T.copy()
+    tex = np.random.RandomState(1).uniform(0, 1, (1, 3, 7)).astype(np.float32)
+    got = render_gpu(ver, tri, tex, H, W)
+    assert (got[3] >= 0).mean() > 0.9
+    assert_render_equal(got, oracle.render_depth(ver, tri, tex, H, W), "big")
+
+
+def test_bad_indices_nan_inf_and_fractional_ids(oracle):
+    rs = np.random.RandomState(5)
+    ver, tri, tex = _random_scene(rs, 2, 80, 160, 24, 24, 3.0)
+    tri[0, 3] = -1            # out of range -> triangle skipped (deviation 3)
+    tri[1, 5] = 80            # == nver
+    tri[2, 7] = 1e9
+    tri[0, 9] = np.nan
+    tri[1, 11] += 0.75        # (int) truncation of float-stored ids
+    ver[0, 0, 5] = np.nan     # NaN x
+    ver[0, 1, 6] = np.inf
+    ver[1, 2, 7] = np.nan     # NaN z -> h NaN -> never drawn
+    ver[1, 2, 8] = -np.inf
+    ver[1, 2, 9] = -3e14      # below the background depth
+    ver[0, 0, 10] = 1e20
+    assert_render_equal(render_gpu(ver, tri, tex, 24, 24), oracle.render_depth(ver, tri, tex, 24, 24), "bad")
+
+
+def test_signed_zero_depth_ties(oracle):
+    # h = -0.0 and +0.0 compare equal in the serial code: lowest index wins
+    ver = np.array([[[1, 6, 1, 1, 6, 1], [1, 1, 6, 1, 1, 6], [-0.0, -0.0, -0.0, 0.0, 0.0, 0.0]]], np.float32)
+    tex = np.ones((1, 3, 6), np.float32)
+    for tri in ([[0, 1, 2], [3, 4, 5]], [[3, 4, 5], [0, 1, 2]]):
+        t = np.array(tri, np.float32).T.copy()
+        got = render_gpu(ver, t, tex, 8, 8)
+        want = oracle.render_depth(ver, t, tex, 8, 8)
+        np.testing.assert_array_equal(got[3], want[3])
+        np.testing.assert_array_equal(got[0], want[0])   # value-equal (+-0)
+
+
+def test_empty_inputs(oracle):
+    ver = np.zeros((2, 3, 5), np.float32)
+    tex = np.zeros((2, 3, 5), np.float32)
+    tri0 = np.zeros((3, 0), np.float32)
+    got = render_gpu(ver, tri0, tex, 6, 9)
+    assert_render_equal(got, oracle.render_depth(ver, tri0, tex, 6, 9), "ntri=0")
+    assert np.all(got[3] == -1) and np.all(got[0] == np.float32(-100000000376832.0))
+    # zero batch / zero-size image: no launch, empty outputs
+    got = render_gpu(np.zeros((0, 3, 5), np.float32), np.zeros((3, 2), np.float32), np.zeros((0, 3, 5), np.float32), 6, 9)
+    assert got[0].shape == (0, 6, 9, 1)
+    got = render_gpu(ver, np.zeros((3, 2), np.float32), tex, 0, 9)
+    assert got[1].shape == (2, 0, 9, 3)
+
+
+def test_argument_errors():
+    from gpu_util import ops
+    o = ops()
+    dev = torch.device("cuda:0")
+    ver = torch.zeros((2, 3, 5), device=dev)
+    tri = torch.zeros((3, 4), device=dev)
+    tex = torch.zeros((2, 3, 5), device=dev)
+    img = torch.zeros((2, 8, 8, 3), device=dev)
+    with pytest.raises(ValueError, match="vertex's batch"):
+        o.render_depth(ver[:1], tri, tex, img)
+    with pytest.raises(ValueError, match="Batch x 3 x nver"):
+        o.render_depth(torch.zeros((2, 2, 5), device=dev), tri, tex, img)
+    with pytest.raises(ValueError, match="3 x ntri"):
+        o.render_depth(ver, torch.zeros((2, 4), device=dev), tex, img)
+    with pytest.raises(ValueError, match="texture channel"):
+        o.render_depth(ver, tri, torch.zeros((2, 4, 5), device=dev), img)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        o.render_depth(ver.cpu(), tri, tex, img)
+    with pytest.raises(TypeError):
+        o.render_depth(ver.double(), tri, tex, img)
+
+
+def test_full_size_face_bit_exact(oracle, full_assets, synth):
+    """BFM-scale mesh (53,215 vertices, 105,840 triangles), 200x200, 2 faces: bit-exact vs the oracle."""
+    A = full_assets
+    P = synth.sample_params_batch(2, beta=0.7, seed=3456)
+    V = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0)
+    want = oracle.render_depth(V, A["tri"], A["vertex"][None], 200, 200)
+    got = render_gpu(V, A["tri"], A["vertex"], 200, 200)
+    assert (want[3] >= 0).mean() > 0.2
+    assert_render_equal(got, want, "full-size")
+
+
+def test_batch64_properties(full_assets, synth, oracle):
+    """BASELINE config 2 size (B=64): determinism, batch-permutation equivariance, and agreement of a few
+    faces with the oracle (the oracle needs ~13 ms/face, so 3 faces)."""
+    A = full_assets
+    P = synth.sample_params_batch(4, beta=0.7, seed=99)
+    V4 = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0)
+    V = np.concatenate([V4] * 16, 0)
+    rs = np.random.RandomState(0)
+    V = V + rs.uniform(-0.3, 0.3, (64, 1, 1)).astype(np.float32)   # distinct faces
+    got1 = render_gpu(V, A["tri"], A["vertex"], 200, 200)
+    got2 = render_gpu(V, A["tri"], A["vertex"], 200, 200)
+    assert_render_equal(got1, got2, "determinism")
+    perm = rs.permutation(64)
+    gotp = render_gpu(V[perm], A["tri"], A["vertex"], 200, 200)
+    assert_render_equal(gotp, tuple(g[perm] for g in got1), "batch permutation")
+    for b in (0, 31, 63):
+        want = oracle.render_depth(V[b:b + 1], A["tri"], A["vertex"][None], 200, 200)
+        assert_render_equal(tuple(g[b:b + 1] for g in got1), want, "face %d" % b)
+    # triangle-order invariance of depth: reversing the triangle list changes tri_ind but not the depth map,
+    # and coverage stays identical
+    tri_rev = np.ascontiguousarray(A["tri"][:, ::-1])
+    gotr = render_gpu(V[:8], tri_rev, A["vertex"], 200, 200)
+    np.testing.assert_array_equal(gotr[0], got1[0][:8])
+    np.testing.assert_array_equal(gotr[3] >= 0, got1[3][:8] >= 0)
