@@ -38,9 +38,9 @@ def test_rendering_layer_wrapper(full_assets, synth):
     pncc, nrm, mask, dimg = net.rendering_layer(V, net.tri, net.vertex_code, im_gray=im)
     assert tuple(pncc.shape) == (2, 200, 200, 3) and tuple(nrm.shape) == (2, 200, 200, 3)
     assert tuple(mask.shape) == (2, 200, 200, 1) and tuple(dimg.shape) == (2, 200, 200, 1)
-    assert float(pncc.min()) >= 1e-6 and float(pncc.max()) <= 1.0
+    assert float(pncc.min()) >= float(np.float32(1e-6)) and float(pncc.max()) <= 1.0
     assert float(nrm[..., 2].min()) >= 0.0
     n2 = (nrm * nrm).sum(-1)
     fg = n2 > 0.5
     assert fg.float().mean() > 0.2 and float((n2[fg] - 1).abs().max()) < 1e-3
-    assert float(dimg.min()) >= 1e-6
+    assert float(dimg.min()) >= float(np.float32(1e-6))
