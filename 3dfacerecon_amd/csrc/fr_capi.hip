@@ -18,8 +18,9 @@ const char* fr_strerror(int code) {
 }
 
 size_t fr_render_depth_workspace_bytes(int B, int nver, int ntri, int H, int W) {
-    (void)B; (void)nver; (void)ntri; (void)H; (void)W;
-    return 0;  // the strip rasteriser keeps its bins in LDS
+    (void)nver;
+    if (B < 0 || ntri < 0 || H < 0 || W < 0) return 0;
+    return fr_render_workspace_bytes_impl(B, ntri, H, W);  // per-segment hit records + bucket offsets
 }
 
 int fr_render_depth_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
@@ -28,11 +29,11 @@ int fr_render_depth_forward(const float* vertex, const float* tri, const float* 
     if (B < 0 || nver < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
     if (C != 3) return FR_ERR_INVALID_ARG;                         // render_depth_op.cc:418
     if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
-    if (ws_bytes < fr_render_depth_workspace_bytes(B, nver, ntri, H, W)) return FR_ERR_WORKSPACE;
     if ((size_t)B * H * W == 0) return FR_OK;                      // empty batch / image: nothing to write
     if (!depth || !tex_img || !normal || !tri_ind) return FR_ERR_INVALID_ARG;
     if (ntri > 0 && (!tri || (nver > 0 && (!vertex || !texture)))) return FR_ERR_INVALID_ARG;
     if (ntri >= (1 << 24)) return FR_ERR_UNSUPPORTED;              // float-stored ids stop being exact
+    if (ws_bytes < fr_render_depth_workspace_bytes(B, nver, ntri, H, W)) return FR_ERR_WORKSPACE;
     return fr_launch_render_forward(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal,
                                     tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream);
 }

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/fr_hotpath.h"
 
@@ -95,6 +97,7 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
                              float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream);
 int fr_launch_render_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
                               int B, int nver, int ntri, int H, int W, hipStream_t stream);
+size_t fr_render_workspace_bytes_impl(int B, int ntri, int H, int W);
 size_t fr_packed_basis_bytes(int N, int n_shape, int n_exp);
 int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
                          void* packed, hipStream_t stream);

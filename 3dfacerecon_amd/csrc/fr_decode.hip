@@ -24,7 +24,7 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int TILE_V = 16;      // vertices per wave tile (MFMA M)
 constexpr int KGROUP = 16;      // k values per packed group (4 k-steps of 4)
 constexpr int MAXB = 64;        // batch columns per pass (4 MFMA column blocks of 16)
-constexpr int DEC_WAVES = 8;    // waves per workgroup
+constexpr int DEC_WAVES = 16;   // waves per workgroup: one persistent workgroup per CU, 4 waves per SIMD
 constexpr int DEC_BLOCK = DEC_WAVES * 64;
 
 __host__ __device__ inline int groups_of(int n) { return (n + KGROUP - 1) / KGROUP; }
@@ -83,6 +83,7 @@ struct DecodeArgs {
     float* out;               // [B,3,N]
     int B, N, ns, ne;
     int b0;                   // first batch column of this pass
+    int halves;               // column-block groups per tile: a work item is (tile, half)
     float im_size;
 };
 
@@ -109,36 +110,101 @@ __device__ void rotation_f64(float phi_f, float gamma_f, float theta_f, float* R
     for (int i = 0; i < 9; i++) R9[i] = (float)Rm[i];
 }
 
-// NB = number of 16-column batch blocks handled (1..4)
-template <int NB>
+// One MFMA k-group: 4 k-steps of v_mfma_f32_16x16x4_f32 for NBW column blocks of one coordinate row-block.
+// The A fragments of the 4 k-steps are passed by value (stay in registers); the B fragments come from LDS.
+template <int NBW>
+struct BFrag;
+template <>
+struct BFrag<1> { typedef float type; };
+template <>
+struct BFrag<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <>
+struct BFrag<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int NBW>
+__device__ __forceinline__ float bsel(const typename BFrag<NBW>::type& b, int i) {
+    if constexpr (NBW == 1) return b;
+    else return b[i];
+}
+template <int NBW>
+__device__ __forceinline__ void mfma_step(float a, const typename BFrag<NBW>::type& bq, f32x4 (&acc)[NBW]) {
+#pragma unroll
+    for (int nb = 0; nb < NBW; nb++)
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bsel<NBW>(bq, nb), acc[nb], 0, 0, 0);
+}
+// Plg points at this lane's B fragment of the group's first k-step; consecutive k-steps are 64 float4 (1 KiB) apart.
+template <int NBW>
+__device__ __forceinline__ typename BFrag<NBW>::type ldb(const float* Plg, int j) {
+    return *reinterpret_cast<const typename BFrag<NBW>::type*>(Plg + (size_t)j * 256);
+}
+template <int NBW>
+__device__ __forceinline__ void mfma_group3(float4 a0, float4 a1, float4 a2, const float* Plg, f32x4 (&acc0)[NBW],
+                                            f32x4 (&acc1)[NBW], f32x4 (&acc2)[NBW]) {
+    typename BFrag<NBW>::type bq = ldb<NBW>(Plg, 0);
+    mfma_step<NBW>(a0.x, bq, acc0); mfma_step<NBW>(a1.x, bq, acc1); mfma_step<NBW>(a2.x, bq, acc2);
+    bq = ldb<NBW>(Plg, 1);
+    mfma_step<NBW>(a0.y, bq, acc0); mfma_step<NBW>(a1.y, bq, acc1); mfma_step<NBW>(a2.y, bq, acc2);
+    bq = ldb<NBW>(Plg, 2);
+    mfma_step<NBW>(a0.z, bq, acc0); mfma_step<NBW>(a1.z, bq, acc1); mfma_step<NBW>(a2.z, bq, acc2);
+    bq = ldb<NBW>(Plg, 3);
+    mfma_step<NBW>(a0.w, bq, acc0); mfma_step<NBW>(a1.w, bq, acc1); mfma_step<NBW>(a2.w, bq, acc2);
+}
+template <int NBW>
+__device__ __forceinline__ void mfma_group1(float4 a0, const float* Plg, f32x4 (&acc0)[NBW]) {
+    mfma_step<NBW>(a0.x, ldb<NBW>(Plg, 0), acc0);
+    mfma_step<NBW>(a0.y, ldb<NBW>(Plg, 1), acc0);
+    mfma_step<NBW>(a0.z, ldb<NBW>(Plg, 2), acc0);
+    mfma_step<NBW>(a0.w, ldb<NBW>(Plg, 3), acc0);
+}
+
+// Persistent kernel: one workgroup per CU (16 waves).  The parameters are laid into LDS once per CU; then every wave
+// walks work items (tile of 16 vertices, group of NBW batch-column blocks).  With B = 64 an item is half a tile
+// (NBW = 2): 6,652 items over 1,024 SIMDs balance to within 8 % of the MFMA floor, where whole tiles (3,326) would leave
+// a quarter of the matrix pipes idle in the last wave-round.  The two halves of a tile are taken by neighbouring waves
+// of the same workgroup at the same time, so the second read of the tile's A fragments is an L1/L2 hit.
+template <int NBW>
 __global__ __launch_bounds__(DEC_BLOCK) void decode_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int GS = groups_of(a.ns), GE = groups_of(a.ne), G = GS + GE;
-    // LDS: Pl[(k)*16 + j] as float4 over nb (k = padded coefficient index, j = column within block), then Mt[64][12]
-    f32x4* Pl = reinterpret_cast<f32x4*>(smem);
+    // LDS: Pl[(k*16 + j)*4 + nb] (k = padded coefficient index, j = column within block, nb = column block), Mt[64][12]
     float* Mt = smem + (size_t)G * KGROUP * 16 * 4;
     const int tid = threadIdx.x;
     const int nd = FR_N_POSE + a.ns + a.ne;
-    const int nbatch = min(a.B - a.b0, 16 * NB);
+    const int nbatch = min(a.B - a.b0, 64);
 
-    for (int i = tid; i < G * KGROUP * 16; i += DEC_BLOCK) {
-        int j = i & 15, k = i >> 4;
-        int g = k / KGROUP, kk = k - g * KGROUP;
-        int col = -1;  // column in the parameter row
-        if (g < GS) {
-            int ks = g * KGROUP + kk;
-            if (ks < a.ns) col = FR_N_POSE + ks;
-        } else {
-            int ke = (g - GS) * KGROUP + kk;
-            if (ke < a.ne) col = FR_N_POSE + a.ns + ke;
-        }
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    // parameters -> LDS in B-fragment order: 16 threads per batch row (1024 = 64 x 16), each walks the row with stride
+    // 16; loads are unconditional (clamped) and batched so they pipeline; padding slots and absent rows are 0.
+    {
+        static_assert(DEC_BLOCK == 1024, "prologue assumes 64 rows x 16 threads");
+        const int bb = tid >> 4, sub = tid & 15;
+        const bool rowok = bb < nbatch;
+        const float* prow = a.params + (size_t)(a.b0 + (rowok ? bb : 0)) * nd + FR_N_POSE;
+        float* dst = smem + (size_t)(bb & 15) * 4 + (bb >> 4);
+        const int KS = GS * KGROUP, KE = GE * KGROUP;
+        if (a.ns > 0) {
+            for (int k0 = sub; k0 < KS; k0 += 128) {
+                float v[8];
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            int bb = 16 * nb + j;
-            if (col >= 0 && bb < nbatch) v[nb] = a.params[(size_t)(a.b0 + bb) * nd + col];
+                for (int u = 0; u < 8; u++) v[u] = prow[min(k0 + 16 * u, a.ns - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = k0 + 16 * u;
+                    if (k < KS) dst[(size_t)k * 64] = (rowok && k < a.ns) ? v[u] : 0.f;
+                }
+            }
         }
-        Pl[i] = v;
+        if (a.ne > 0) {
+            for (int k0 = sub; k0 < KE; k0 += 128) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = prow[a.ns + min(k0 + 16 * u, a.ne - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = k0 + 16 * u;
+                    if (k < KE) dst[(size_t)(KS + k) * 64] = (rowok && k < a.ne) ? v[u] : 0.f;
+                }
+            }
+        }
     }
     if (tid < 64) {
         float m[12];
@@ -168,73 +234,82 @@ __global__ __launch_bounds__(DEC_BLOCK) void decode_kernel(DecodeArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int tiles = tiles_of(a.N);
     const int N = a.N;
-    for (int tile = blockIdx.x * DEC_WAVES + wave; tile < tiles; tile += gridDim.x * DEC_WAVES) {
-        const float4* Ap = a.A + (size_t)tile * G * 3 * 64 + lane;
-        f32x4 acc[3][NB];
+    const int H2 = a.halves;
+    const long long items = (long long)tiles * H2;
+    // item = tile * halves + half; waves 2k and 2k+1 of a workgroup take neighbouring items (same tile when halves = 2)
+    for (long long it = (long long)blockIdx.x * DEC_WAVES + wave; it < items; it += (long long)gridDim.x * DEC_WAVES) {
+        const int tile = (int)(it / H2);
+        const int hf = (int)(it - (long long)tile * H2);
+        const float4* Ap = a.A + (size_t)tile * G * 3 * 64 + lane;  // group g, coordinate c at Ap[(g*3+c)*64]
+        const float* Pll = smem + (size_t)lane * 4 + hf * NBW;       // this lane's B fragment, k-step 0
+        f32x4 acc0[NBW], acc1[NBW], acc2[NBW];
 #pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) acc[c][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NBW; nb++) acc0[nb] = acc1[nb] = acc2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        // ---- S = pc_shape . alpha : fmaf chain over k, from +0 ----
+        // ---- S = pc_shape . alpha : fmaf chain over k from +0; A fragments double-buffered in registers so the
+        //      next group's 3 KiB are in flight while the current group's MFMAs issue ----
+        // two groups (6 KiB per wave, ~96 KiB per CU) are kept in flight: a round of the SIMD's four waves through
+        // one group is ~1.8 us at the clock the chip holds under MFMA load, about one HBM round trip.
+        float4 c0 = Ap[0], c1 = Ap[64], c2 = Ap[128];
+        const int g1 = G > 1 ? 1 : 0;
+        float4 d0 = Ap[(size_t)(g1 * 3 + 0) * 64], d1 = Ap[(size_t)(g1 * 3 + 1) * 64], d2 = Ap[(size_t)(g1 * 3 + 2) * 64];
         for (int g = 0; g < GS; g++) {
-            float4 a0 = Ap[(size_t)(g * 3 + 0) * 64];
-            float4 a1 = Ap[(size_t)(g * 3 + 1) * 64];
-            float4 a2 = Ap[(size_t)(g * 3 + 2) * 64];
-            const float av[3][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}, {a2.x, a2.y, a2.z, a2.w}};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                f32x4 bq = Pl[(size_t)(g * 4 + j) * 64 + lane];
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++)
-                        acc[c][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][j], bq[nb], acc[c][nb], 0, 0, 0);
-            }
+            const int gn = g + 2 < G ? g + 2 : G - 1;  // the last S groups prefetch the first E groups
+            const float4 n0 = Ap[(size_t)(gn * 3 + 0) * 64], n1 = Ap[(size_t)(gn * 3 + 1) * 64],
+                         n2 = Ap[(size_t)(gn * 3 + 2) * 64];
+            mfma_group3<NBW>(c0, c1, c2, Pll + (size_t)g * 1024, acc0, acc1, acc2);
+            c0 = d0; c1 = d1; c2 = d2;
+            d0 = n0; d1 = n1; d2 = n2;
         }
         // v = mu + S   (network.py:159, first add)
-        f32x4 v[3][NB];
+        {
+            const float* mp = a.mu_p + (size_t)tile * 3 * TILE_V + 4 * (lane >> 4);
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(mp);
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(mp + TILE_V);
+            const f32x4 m2 = *reinterpret_cast<const f32x4*>(mp + 2 * TILE_V);
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            f32x4 m4 = *reinterpret_cast<const f32x4*>(a.mu_p + ((size_t)tile * 3 + c) * TILE_V + 4 * (lane >> 4));
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) {
-                v[c][nb] = m4 + acc[c][nb];
-                acc[c][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nb = 0; nb < NBW; nb++) {
+                acc0[nb] = m0 + acc0[nb];
+                acc1[nb] = m1 + acc1[nb];
+                acc2[nb] = m2 + acc2[nb];
             }
         }
-        // ---- E = pc_exp . beta ----
-        for (int g = GS; g < G; g++) {
-            float4 a0 = Ap[(size_t)(g * 3 + 0) * 64];
-            float4 a1 = Ap[(size_t)(g * 3 + 1) * 64];
-            float4 a2 = Ap[(size_t)(g * 3 + 2) * 64];
-            const float av[3][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}, {a2.x, a2.y, a2.z, a2.w}};
+        // ---- E = pc_exp . beta, one coordinate at a time (only NBW extra accumulators live), then
+        //      v = (mu + S) + E ----
+        {
+            f32x4 e[NBW];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                f32x4 bq = Pl[(size_t)(g * 4 + j) * 64 + lane];
+            for (int nb = 0; nb < NBW; nb++) e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (GE > 0) mfma_group1<NBW>(c0, Pll + (size_t)GS * 1024, e);
+            if (GE > 1) mfma_group1<NBW>(d0, Pll + (size_t)(GS + 1) * 1024, e);
+            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 0) * 64], Pll + (size_t)g * 1024, e);
 #pragma unroll
-                for (int c = 0; c < 3; c++)
+            for (int nb = 0; nb < NBW; nb++) { acc0[nb] = acc0[nb] + e[nb]; e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            if (GE > 0) mfma_group1<NBW>(c1, Pll + (size_t)GS * 1024, e);
+            if (GE > 1) mfma_group1<NBW>(d1, Pll + (size_t)(GS + 1) * 1024, e);
+            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 1) * 64], Pll + (size_t)g * 1024, e);
 #pragma unroll
-                    for (int nb = 0; nb < NB; nb++)
-                        acc[c][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][j], bq[nb], acc[c][nb], 0, 0, 0);
-            }
+            for (int nb = 0; nb < NBW; nb++) { acc1[nb] = acc1[nb] + e[nb]; e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            if (GE > 0) mfma_group1<NBW>(c2, Pll + (size_t)GS * 1024, e);
+            if (GE > 1) mfma_group1<NBW>(d2, Pll + (size_t)(GS + 1) * 1024, e);
+            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 2) * 64], Pll + (size_t)g * 1024, e);
+#pragma unroll
+            for (int nb = 0; nb < NBW; nb++) acc2[nb] = acc2[nb] + e[nb];
         }
-        // ---- fused epilogue: (+E), 3x3 (f.R) transform, +t3d, y flip, store [B,3,N] ----
+        // ---- fused epilogue: 3x3 (f.R) transform, +t3d, y flip, store [B,3,N] ----
         const int p0 = tile * TILE_V + 4 * (lane >> 4);  // first of this lane's 4 vertices
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-            const int bb = 16 * nb + (lane & 15);
+        for (int nb = 0; nb < NBW; nb++) {
+            const int bb = 16 * (hf * NBW + nb) + (lane & 15);
             if (bb >= nbatch) continue;
             const float* m = Mt + bb * 12;
             f32x4 px, py, pz;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float vx = v[0][nb][r] + acc[0][nb][r];  // (mu + S) + E
-                float vy = v[1][nb][r] + acc[1][nb][r];
-                float vz = v[2][nb][r] + acc[2][nb][r];
-                float qx = __builtin_fmaf(m[2], vz, __builtin_fmaf(m[1], vy, m[0] * vx)) + m[9];
-                float qy = __builtin_fmaf(m[5], vz, __builtin_fmaf(m[4], vy, m[3] * vx)) + m[10];
-                float qz = __builtin_fmaf(m[8], vz, __builtin_fmaf(m[7], vy, m[6] * vx)) + m[11];
+                const float vx = acc0[nb][r], vy = acc1[nb][r], vz = acc2[nb][r];
+                const float qx = __builtin_fmaf(m[2], vz, __builtin_fmaf(m[1], vy, m[0] * vx)) + m[9];
+                const float qy = __builtin_fmaf(m[5], vz, __builtin_fmaf(m[4], vy, m[3] * vx)) + m[10];
+                const float qz = __builtin_fmaf(m[8], vz, __builtin_fmaf(m[7], vy, m[6] * vx)) + m[11];
                 px[r] = qx;
                 py[r] = (a.im_size - qy) - 1.0f;  // network.py:168
                 pz[r] = qz;
@@ -282,12 +357,24 @@ int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
-template <int NB>
-static int launch_decode_nb(const fr::DecodeArgs& a, size_t lds, int grid, hipStream_t stream) {
+static int device_cu_count() {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+template <int NBW>
+static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int grid, hipStream_t stream) {
     static unsigned char lds_ok[64];
-    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_kernel<NB>), lds_ok) != hipSuccess)
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_kernel<NBW>), lds_ok) != hipSuccess)
         return FR_ERR_LAUNCH;
-    hipLaunchKernelGGL(fr::decode_kernel<NB>, dim3(grid), dim3(fr::DEC_BLOCK), lds, stream, a);
+    hipLaunchKernelGGL(fr::decode_kernel<NBW>, dim3(grid), dim3(fr::DEC_BLOCK), lds, stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
@@ -307,18 +394,15 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
     a.out = vertex_proj;
     a.B = B; a.N = N; a.ns = n_shape; a.ne = n_exp;
     a.im_size = im_size;
-    int grid = (int)((tiles + DEC_WAVES - 1) / DEC_WAVES);
-    if (grid > 512) grid = 512;
+    const int cus = device_cu_count();
     for (int b0 = 0; b0 < B; b0 += MAXB) {
         a.b0 = b0;
-        int nb = (min(B - b0, MAXB) + 15) / 16;
-        int rc;
-        switch (nb) {
-            case 1: rc = launch_decode_nb<1>(a, lds, grid, stream); break;
-            case 2: rc = launch_decode_nb<2>(a, lds, grid, stream); break;
-            case 3: rc = launch_decode_nb<3>(a, lds, grid, stream); break;
-            default: rc = launch_decode_nb<4>(a, lds, grid, stream); break;
-        }
+        const int nbt = (min(B - b0, MAXB) + 15) / 16;  // 16-column blocks in this pass (1..4)
+        const int nbw = nbt == 1 ? 1 : 2;               // column blocks per work item
+        a.halves = (nbt + nbw - 1) / nbw;
+        long long items = (long long)tiles * a.halves;
+        int grid = (int)min((long long)cus, (items + DEC_WAVES - 1) / DEC_WAVES);
+        int rc = nbw == 1 ? launch_decode_nbw<1>(a, lds, grid, stream) : launch_decode_nbw<2>(a, lds, grid, stream);
         if (rc != FR_OK) return rc;
     }
     return FR_OK;

@@ -4,18 +4,28 @@
 // (forward) and :325-368 (backward) -- NOT the reference's CUDA kernels (render_depth_op.cu.cc:176-237 race
 // on the z-test and are not the numerical spec).
 //
-// How (MI355X-first, nothing like the reference's three-kernel + 705 MB fp64 scratch pipeline):
-//   * one workgroup owns one (face, strip-of-rows) screen bin; the bin's per-pixel 64-bit keys live in LDS
-//     (rows*W*8 bytes, up to the whole 160 KiB of a CU);
-//   * every lane takes a triangle, gathers its vertices from the face's [3,nver] planes (L2-resident: 638 KB
-//     per face), rejects on the strip / bbox with the reference's exact integer rules, runs the fp64
-//     barycentric test for the few pixel centres in its bbox and resolves depth with one LDS ds_max_u64 per
-//     hit: max over (orderable(h) << 32 | ~tri) == "largest h, ties to the lowest index" -- deterministic
-//     and order independent, so no global atomics and no races;
-//   * the same workgroup then unpacks the winners and streams the four output planes of its strip with
-//     16-byte stores; per-triangle texture means and normals are recomputed from the winner's vertices
-//     instead of being materialised per triangle.
-// Bound: HBM (1.28 MB of output per face is the dominant algorithmic traffic); see DESIGN.md.
+// How (MI355X-first, nothing like the reference's three-kernel + 705 MB fp64 scratch pipeline).  At BFM density
+// triangles are sub-pixel (about half have no pixel centre in their bbox, the rest test ~1 pixel), so the work is
+// "gather 9 floats, maybe emit one hit", then "per-pixel max":
+//
+//   raster_emit_kernel   one lane per (face, triangle), 256-triangle segments, ~26 k small workgroups so that the
+//                        dependent idx -> vertex gathers are hidden by occupancy.  Applies the reference's exact
+//                        integer bbox / whole-triangle-reject rules, computes the fp32 centroid depth and runs the
+//                        fp64 barycentric test on the bbox's pixel centres.  A triangle whose bbox fits an 8x4
+//                        window inside one screen strip emits ONE 16-byte record {key, x0|y0, 32-bit hit mask};
+//                        anything else (large or strip-straddling) emits a "big" record that the resolver
+//                        rasterises itself.  Records are counting-sorted by screen strip inside the segment through
+//                        LDS counters -- no global atomics, no global counters to zero, fixed capacity.
+//   resolve_write_kernel one workgroup per (face, strip-of-rows) screen bin; the bin's 64-bit keys live in LDS
+//                        (rows*W*8 B).  It pulls only its own bucket of every segment, resolves with ds_max_u64 on
+//                        key = orderable(h) << 32 | ~tri  (max == "largest h, ties to the lowest index": the serial
+//                        semantics, order independent => deterministic, race free), then unpacks the winners and
+//                        streams the four output planes of its strip with 16-byte stores; texture means and
+//                        normals are recomputed from the winner's vertices, never materialised per triangle.
+//   render_strip_kernel  the first-generation path (every bin scans every triangle); kept as the general fallback
+//                        for shapes the binned path does not cover and for A/B runs (FR_RENDER_IMPL=scan).
+//
+// Bound: HBM -- 1.28 MB of output planes per face is the dominant algorithmic traffic.
 #include "fr_common.h"
 
 namespace fr {
@@ -32,14 +42,63 @@ struct RenderArgs {
     int rows;              // rows per strip
     int strips;            // strips per face
     long long tex_stride;  // 0 (shared texture) or 3*nver
+    // binned path workspace
+    uint4* recs;           // [B][nseg][SEG] records
+    uint16_t* segoff;      // [B][nseg][OFF_STRIDE] bucket offsets
+    float4* nrm_ws;        // [B][ntri]   un-normalised normal (xyz) of every emitting triangle
+    float4* tritex_ws;     // [tex_batch][ntri] per-triangle texture mean (one copy when the texture is shared)
+    int nseg;
+    float wm1, hm1;        // (float)(W-1), (float)(H-1)
+    uint32_t rows_magic;   // ceil(2^32 / rows): y / rows == umulhi(y, magic) for y, rows < 2^16
+    int dbg;               // diagnostic ablation mask (FR_RENDER_DBG), 0 in production
 };
 
+constexpr int SEG = 256;         // triangles (and record capacity) per segment
+constexpr int OFF_STRIDE = 64;   // u16 offsets per segment (strips + 1 <= 64)
+constexpr int MAX_STRIPS = OFF_STRIDE - 1;
+constexpr int SMALL_W = 8, SMALL_H = 4;  // hit-mask window: bit = dy*8 + dx
+
 // XCD-aware block remap (bijective for any grid): blocks that share blockIdx%8 share an XCD/L2, so give each
-// XCD a contiguous run of (face, strip) bins -- all strips of a face then hit one L2 with that face's vertices.
+// XCD a contiguous run of bins -- all work on a face then meets that face's vertices (and records) in one L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
+}
+
+// One triangle against one strip [r0, r1): the reference's per-triangle body (render_depth_op.cc:201-219, 263-316)
+// with the depth test replaced by the packed-key LDS max.
+__device__ __forceinline__ void raster_triangle_into_strip(int t, const float* __restrict__ tri,
+                                                           const float* __restrict__ vx, const float* __restrict__ vy,
+                                                           const float* __restrict__ vz, int nver, int ntri, int H,
+                                                           int W, int r0, int r1, unsigned long long* keys) {
+    // vertex ids: (int) truncation of float-stored indices, render_depth_op.cc:204-206
+    int p1 = f2i_x86(tri[t]);
+    int p2 = f2i_x86(tri[(size_t)ntri + t]);
+    int p3 = f2i_x86(tri[2 * (size_t)ntri + t]);
+    if ((unsigned)p1 >= (unsigned)nver || (unsigned)p2 >= (unsigned)nver || (unsigned)p3 >= (unsigned)nver)
+        return;  // deviation 3: the reference would read out of bounds
+    float y1 = vy[p1], y2 = vy[p2], y3 = vy[p3];
+    int y_min = f2i_x86(ceilf(mn(mn(y1, y2), y3)));   // render_depth_op.cc:279-280
+    int y_max = f2i_x86(floorf(mx(mx(y1, y2), y3)));
+    if (y_max < y_min || y_max > H - 1 || y_min < 0) return;  // part of the whole-triangle reject, :282
+    int ya = max(y_min, r0), yb = min(y_max, r1 - 1);
+    if (ya > yb) return;
+    float x1 = vx[p1], x2 = vx[p2], x3 = vx[p3];
+    int x_min = f2i_x86(ceilf(mn(mn(x1, x2), x3)));   // :276-277
+    int x_max = f2i_x86(floorf(mx(mx(x1, x2), x3)));
+    if (x_max < x_min || x_max > W - 1 || x_min < 0) return;  // :282
+    float h = ((vz[p1] + vz[p2]) + vz[p3]) / 3.0f;    // centroid depth in fp32, :217
+    h = h + 0.0f;                                     // -0 -> +0 (the serial code treats them as equal)
+    if (!(h > bg_depth())) return;                    // NaN or <= background can never pass 'depth < h' (:295)
+    const unsigned long long key = make_key(h, t);
+    const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
+    for (int y = ya; y <= yb; y++) {
+        unsigned long long* row = keys + (size_t)(y - r0) * W;
+        for (int x = x_min; x <= x_max; x++) {
+            if (point_in_tri(ts, x, y)) atomicMax(&row[x], key);
+        }
+    }
 }
 
 struct PixelOut {
@@ -81,74 +140,128 @@ __device__ __forceinline__ PixelOut resolve_pixel(unsigned long long key, const 
     return o;
 }
 
+// resolve + write the strip's four planes from the LDS keys (16-byte stores when the strip is 4-pixel aligned)
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void render_strip_kernel(RenderArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+__device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, int npix,
+                                            const unsigned long long* keys, const float* __restrict__ vx,
+                                            const float* __restrict__ vy, const float* __restrict__ vz) {
     const int tid = threadIdx.x;
-    const int bin = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = bin / a.strips;
-    const int s = bin - b * a.strips;
-    const int r0 = s * a.rows;
-    const int r1 = min(a.H, r0 + a.rows);
-    const int W = a.W, H = a.H, nver = a.nver, ntri = a.ntri;
-    const int npix = (r1 - r0) * W;
-
-    const unsigned long long KBG = bg_key();
-    for (int i = tid; i < npix; i += BLOCK) keys[i] = KBG;
-    __syncthreads();
-
-    const float* __restrict__ vx = a.vertex + (size_t)b * 3 * nver;
-    const float* __restrict__ vy = vx + nver;
-    const float* __restrict__ vz = vy + nver;
+    const int nver = a.nver, ntri = a.ntri;
     const float* __restrict__ tri = a.tri;
-
-    for (int t = tid; t < ntri; t += BLOCK) {
-        // vertex ids: (int) truncation of float-stored indices, render_depth_op.cc:204-206
-        int p1 = f2i_x86(tri[t]);
-        int p2 = f2i_x86(tri[(size_t)ntri + t]);
-        int p3 = f2i_x86(tri[2 * (size_t)ntri + t]);
-        if ((unsigned)p1 >= (unsigned)nver || (unsigned)p2 >= (unsigned)nver || (unsigned)p3 >= (unsigned)nver)
-            continue;  // deviation 3: the reference would read out of bounds
-        // rows first: most triangles miss this strip
-        float y1 = vy[p1], y2 = vy[p2], y3 = vy[p3];
-        int y_min = f2i_x86(ceilf(mn(mn(y1, y2), y3)));   // render_depth_op.cc:279-280
-        int y_max = f2i_x86(floorf(mx(mx(y1, y2), y3)));
-        if (y_max < y_min || y_max > H - 1 || y_min < 0) continue;  // part of the whole-triangle reject, :282
-        int ya = max(y_min, r0), yb = min(y_max, r1 - 1);
-        if (ya > yb) continue;
-        float x1 = vx[p1], x2 = vx[p2], x3 = vx[p3];
-        int x_min = f2i_x86(ceilf(mn(mn(x1, x2), x3)));   // :276-277
-        int x_max = f2i_x86(floorf(mx(mx(x1, x2), x3)));
-        if (x_max < x_min || x_max > W - 1 || x_min < 0) continue;  // :282
-        // centroid depth in fp32, :217
-        float h = ((vz[p1] + vz[p2]) + vz[p3]) / 3.0f;
-        h = h + 0.0f;                   // -0 -> +0 (serial code treats them as equal)
-        if (!(h > bg_depth())) continue;  // NaN or <= background can never pass 'depth < h' (:295)
-        const unsigned long long key = make_key(h, t);
-        const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
-        for (int y = ya; y <= yb; y++) {
-            unsigned long long* row = keys + (size_t)(y - r0) * W;
-            for (int x = x_min; x <= x_max; x++) {
-                if (point_in_tri(ts, x, y)) atomicMax(&row[x], key);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- resolve + write the strip's four planes -------------------------------------------------------
     const float* __restrict__ tex = a.texture + (size_t)b * a.tex_stride;
-    const size_t pix0 = ((size_t)b * H + r0) * W;  // first pixel of the strip in the [B,H,W] planes
+    const size_t pix0 = ((size_t)b * a.H + r0) * a.W;  // first pixel of the strip in the [B,H,W] planes
     float* dep = a.depth + pix0;
     float* tin = a.tri_ind + pix0;
     float* txi = a.tex_img + pix0 * 3;
     float* nrm = a.normal + pix0 * 3;
     const bool vec_ok = ((npix & 3) == 0) && ((pix0 & 3) == 0) &&
                         ((((uintptr_t)a.depth | (uintptr_t)a.tri_ind | (uintptr_t)a.tex_img | (uintptr_t)a.normal) & 15) == 0);
-    if (vec_ok) {
-        for (int g = tid; g < (npix >> 2); g += BLOCK) {
-            PixelOut o[4];
+    if (a.nrm_ws != nullptr && ntri > 0 && !(a.dbg & 8)) {
+        // binned path: the emit kernel left each emitting triangle's normal and texture mean in the workspace as
+        // float4 tables indexed by triangle id, so a covered pixel costs two 16-byte loads.  One pixel per lane:
+        // neighbouring lanes hold neighbouring pixels -> neighbouring triangles -> shared cache lines.
+        const float4* __restrict__ nws = a.nrm_ws + (size_t)b * ntri;
+        const float4* __restrict__ tws = a.tritex_ws + (a.tex_stride ? (size_t)b * ntri : 0);
+        const unsigned long long KBG = bg_key();
+        // UNR pixels per lane per trip, all table loads issued before the first store: the tables were written by
+        // the emit kernel a moment ago and mostly come from HBM / Infinity Cache, so latency is paid once per trip.
+        constexpr int UNR = 4;
+        for (int i0 = tid; i0 < npix; i0 += BLOCK * UNR) {
+            unsigned long long kk[UNR];
+            bool cov[UNR];
+            int t[UNR];
+            float4 nv[UNR], tv[UNR];
 #pragma unroll
-            for (int k = 0; k < 4; k++) o[k] = resolve_pixel(keys[4 * g + k], vx, vy, vz, tri, tex, nver, ntri);
+            for (int u = 0; u < UNR; u++) {
+                const int i = i0 + u * BLOCK;
+                kk[u] = (i < npix) ? keys[i] : KBG;
+                cov[u] = kk[u] != KBG;
+                t[u] = cov[u] ? (int)(0xFFFFFFFFu - (uint32_t)kk[u]) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                nv[u] = nws[t[u]];
+                tv[u] = tws[t[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int i = i0 + u * BLOCK;
+                if (i < npix) {
+                    dep[i] = cov[u] ? f32_unord((uint32_t)(kk[u] >> 32)) : bg_depth();
+                    tin[i] = cov[u] ? (float)t[u] : -1.0f;
+                    float* tp = txi + 3 * (size_t)i;
+                    float* np = nrm + 3 * (size_t)i;
+                    tp[0] = cov[u] ? tv[u].x : 0.0f;
+                    tp[1] = cov[u] ? tv[u].y : 0.0f;
+                    tp[2] = cov[u] ? tv[u].z : 0.0f;
+                    np[0] = cov[u] ? nv[u].x : 0.0f;
+                    np[1] = cov[u] ? nv[u].y : 0.0f;
+                    np[2] = cov[u] ? nv[u].z : 0.0f;
+                }
+            }
+        }
+    } else if (vec_ok) {
+        // Four consecutive pixels per lane (16-byte stores).  The winner's data sits two dependent gathers away
+        // (key -> vertex ids -> positions / texture); all loads of the four pixels are issued together and
+        // unconditionally (background pixels read triangle 0 with clamped ids and discard it), so a pass costs two
+        // memory round trips instead of eight.
+        const bool can_gather = ntri > 0 && nver > 0 && !(a.dbg & 8);
+        const unsigned long long KBG = bg_key();
+        for (int g = tid; g < (npix >> 2); g += BLOCK) {
+            unsigned long long kk[4];
+            bool cov[4];
+            int t[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                kk[k] = keys[4 * g + k];
+                cov[k] = can_gather && kk[k] != KBG;
+                t[k] = cov[k] ? (int)(0xFFFFFFFFu - (uint32_t)kk[k]) : 0;
+            }
+            PixelOut o[4];
+            if (can_gather) {
+                int p[4][3];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        int q = (int)tri[(size_t)c * ntri + t[k]];
+                        p[k][c] = min(max(q, 0), nver - 1);  // no-op for winners (their ids passed the bounds test)
+                    }
+                float P[4][3][3], T[4][3][3];  // [pixel][coord / channel][vertex]
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float* vc = vx + (size_t)c * nver;
+                        const float* tc = tex + (size_t)c * nver;
+#pragma unroll
+                        for (int v = 0; v < 3; v++) {
+                            P[k][c][v] = vc[p[k][v]];
+                            T[k][c][v] = tc[p[k][v]];
+                        }
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    o[k].depth = cov[k] ? f32_unord((uint32_t)(kk[k] >> 32)) : bg_depth();
+                    o[k].tind = cov[k] ? (float)t[k] : -1.0f;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        float m = ((T[k][c][0] + T[k][c][1]) + T[k][c][2]) / 3.0f;  // fp32, render_depth_op.cc:223
+                        o[k].tex[c] = cov[k] ? m : 0.0f;
+                    }
+                    // differences in fp32, cross product in fp64 without FMA (render_depth_op.cc:227-236, 308)
+                    double ax = (double)(P[k][0][0] - P[k][0][1]), ay = (double)(P[k][1][0] - P[k][1][1]),
+                           az = (double)(P[k][2][0] - P[k][2][1]);
+                    double bx = (double)(P[k][0][0] - P[k][0][2]), by = (double)(P[k][1][0] - P[k][1][2]),
+                           bz = (double)(P[k][2][0] - P[k][2][2]);
+                    o[k].nrm[0] = cov[k] ? (float)(ay * bz - az * by) : 0.0f;
+                    o[k].nrm[1] = cov[k] ? (float)(az * bx - ax * bz) : 0.0f;
+                    o[k].nrm[2] = cov[k] ? (float)(ax * by - ay * bx) : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = resolve_pixel(KBG, vx, vy, vz, tri, tex, nver, ntri);
+            }
             reinterpret_cast<float4*>(dep)[g] = make_float4(o[0].depth, o[1].depth, o[2].depth, o[3].depth);
             reinterpret_cast<float4*>(tin)[g] = make_float4(o[0].tind, o[1].tind, o[2].tind, o[3].tind);
             float4* t4 = reinterpret_cast<float4*>(txi) + 3 * (size_t)g;
@@ -172,6 +285,269 @@ __global__ __launch_bounds__(BLOCK) void render_strip_kernel(RenderArgs a) {
             }
         }
     }
+}
+
+// ---- first-generation path: every (face, strip) bin scans every triangle ---------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void render_strip_kernel(RenderArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int tid = threadIdx.x;
+    const int bin = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bin / a.strips;
+    const int s = bin - b * a.strips;
+    const int r0 = s * a.rows;
+    const int r1 = min(a.H, r0 + a.rows);
+    const int npix = (r1 - r0) * a.W;
+    const unsigned long long KBG = bg_key();
+    for (int i = tid; i < npix; i += BLOCK) keys[i] = KBG;
+    __syncthreads();
+    const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.nver;
+    const float* __restrict__ vy = vx + a.nver;
+    const float* __restrict__ vz = vy + a.nver;
+    for (int t = tid; t < a.ntri; t += BLOCK)
+        raster_triangle_into_strip(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, a.W, r0, r1, keys);
+    __syncthreads();
+    write_strip<BLOCK>(a, b, r0, npix, keys, vx, vy, vz);
+}
+
+// ---- binned path, kernel 1: per-triangle setup + hit test, records counting-sorted by strip -----------------
+// record = {key.lo, key.hi, x0 | y0 << 16, mask}; mask != 0: hit bits (dy*8+dx) of an 8x4 window at (x0,y0) that lies
+// inside one strip; mask == 0: "big" record, the resolver rasterises triangle ~key.lo itself.
+// bucket order inside a segment: [big | strip 0 | strip 1 | ...]; segoff[0] = #big = start of strip 0,
+// segoff[s+1] = end of strip s.
+// 32-bit-offset gather: base pointer stays in SGPRs, one VALU shift per address (ids < 2^30 by construction).
+__device__ __forceinline__ float ld_off(const float* __restrict__ base, uint32_t idx) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)(idx << 2));
+}
+// float-stored id -> int with the reference's truncation; false for NaN / negative / >= n (x86 cvttss2si would give
+// INT_MIN there, which is out of range too).  (-1,0) truncates to 0 like (int) does.
+__device__ __forceinline__ bool id_ok(float f, int n, int& p) {
+    p = (int)f;  // saturating, NaN -> 0
+    return (f > -1.0f) && ((unsigned)p < (unsigned)n);
+}
+
+__global__ __launch_bounds__(SEG) void raster_emit_kernel(RenderArgs a) {
+    __shared__ uint32_t cnt[OFF_STRIDE];
+    __shared__ uint32_t base[OFF_STRIDE];
+    const int tid = threadIdx.x;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / a.nseg;
+    const int seg = lid - b * a.nseg;
+    const int t = seg * SEG + tid;
+    const int S = a.strips;
+    if (tid <= S) cnt[tid] = 0;
+    __syncthreads();
+
+    const int nver = a.nver, ntri = a.ntri;
+    const float* __restrict__ vx = a.vertex + (size_t)b * 3 * nver;
+    const float* __restrict__ vy = vx + nver;
+    const float* __restrict__ vz = vy + nver;
+    bool emit = false;
+    int bucket = 0;
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (t < ntri) {
+        int p1, p2, p3;
+        const bool ok1 = id_ok(ld_off(a.tri, (uint32_t)t), nver, p1);
+        const bool ok2 = id_ok(ld_off(a.tri + ntri, (uint32_t)t), nver, p2);
+        const bool ok3 = id_ok(ld_off(a.tri + 2 * (size_t)ntri, (uint32_t)t), nver, p3);
+        if (a.dbg & 128) { p1 = t % nver; p2 = (t + 1) % nver; p3 = (t + 2) % nver; }
+        if (ok1 && ok2 && ok3) {  // else deviation 3: the reference would read out of bounds
+            // all nine gathers are independent once the ids are known: issue them together
+            const float x1 = ld_off(vx, p1), x2 = ld_off(vx, p2), x3 = ld_off(vx, p3);
+            const float y1 = ld_off(vy, p1), y2 = ld_off(vy, p2), y3 = ld_off(vy, p3);
+            const float z1 = ld_off(vz, p1), z2 = ld_off(vz, p2), z3 = ld_off(vz, p3);
+            // bbox = ceil(min) .. floor(max) per axis and the whole-triangle reject of render_depth_op.cc:276-283, in the
+            // float domain: a NaN coordinate makes PointInTri false for every pixel whatever the bbox (all dot products
+            // turn NaN), so the NaN-ignoring v_min3/v_max3 are equivalent to the reference's macros here; the negated
+            // comparisons reject NaN / +-inf / out-of-int-range bounds exactly where (int) gives INT_MIN on x86.
+            const float fx0 = ceilf(fminf(fminf(x1, x2), x3)), fx1 = floorf(fmaxf(fmaxf(x1, x2), x3));
+            const float fy0 = ceilf(fminf(fminf(y1, y2), y3)), fy1 = floorf(fmaxf(fmaxf(y1, y2), y3));
+            const bool xy_nan = (x1 != x1) || (x2 != x2) || (x3 != x3) || (y1 != y1) || (y2 != y2) || (y3 != y3);
+            bool rej = !(fx0 >= 0.0f) || !(fy0 >= 0.0f) || !(fx1 <= a.wm1) || !(fy1 <= a.hm1) || (fx1 < fx0) ||
+                       (fy1 < fy0) || xy_nan;
+            if (a.dbg & 32) { asm volatile("" ::"v"(z1), "v"(z2), "v"(z3)); rej = true; }
+            float h = ((z1 + z2) + z3) / 3.0f;  // fp32 centroid depth, :217
+            h = h + 0.0f;                        // -0 -> +0
+            if (!rej && (h > bg_depth())) {      // NaN or <= background never passes 'depth < h' (:295)
+                const int x_min = (int)fx0, x_max = (int)fx1, y_min = (int)fy0, y_max = (int)fy1;
+                const unsigned long long key = make_key(h, t);
+                rec.x = (uint32_t)key;
+                rec.y = (uint32_t)(key >> 32);
+                rec.z = (uint32_t)x_min | ((uint32_t)y_min << 16);
+                // strip of the first / last row: y / rows through the exact 2^32 reciprocal (y, rows < 2^16)
+                const int s0 = a.rows_magic ? (int)__umulhi((uint32_t)y_min, a.rows_magic) : y_min;
+                const int s1 = a.rows_magic ? (int)__umulhi((uint32_t)y_max, a.rows_magic) : y_max;
+                if (x_max - x_min < SMALL_W && y_max - y_min < SMALL_H && s0 == s1) {
+                    const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
+                    uint32_t m = 0;
+                    for (int y = y_min; y <= y_max; y++)
+                        for (int x = x_min; x <= x_max; x++)
+                            if (point_in_tri(ts, x, y)) m |= 1u << ((y - y_min) * SMALL_W + (x - x_min));
+                    rec.w = m;
+                    emit = (m != 0);
+                    bucket = 1 + s0;
+                } else {
+                    rec.w = 0;
+                    emit = true;
+                    bucket = 0;
+                }
+                if (emit && !(a.dbg & 64)) {
+                    // un-normalised normal (p1-p2) x (p1-p3): fp32 differences, fp64 products without FMA, one
+                    // rounding (render_depth_op.cc:227-236, 308) -- computed here, where the vertices are in registers
+                    double ax = (double)(x1 - x2), ay = (double)(y1 - y2), az = (double)(z1 - z2);
+                    double bx = (double)(x1 - x3), by = (double)(y1 - y3), bz = (double)(z1 - z3);
+                    a.nrm_ws[(size_t)b * ntri + t] = make_float4((float)(ay * bz - az * by), (float)(az * bx - ax * bz),
+                                                                 (float)(ax * by - ay * bx), 0.0f);
+                }
+            }
+            // per-triangle texture mean ((t1+t2)+t3)/3 in fp32 (render_depth_op.cc:223): per face when every face has
+            // its own texture, otherwise once (by face 0's workgroups) for all faces
+            if (a.tex_stride ? emit : (b == 0)) {
+                const float* __restrict__ tex = a.texture + (size_t)b * a.tex_stride;
+                float tm[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const float* tj = tex + (size_t)j * nver;
+                    tm[j] = ((ld_off(tj, p1) + ld_off(tj, p2)) + ld_off(tj, p3)) / 3.0f;
+                }
+                a.tritex_ws[(size_t)(a.tex_stride ? b : 0) * ntri + t] = make_float4(tm[0], tm[1], tm[2], 0.0f);
+            }
+        }
+    }
+    uint32_t pos = 0;
+    if (emit) pos = atomicAdd(&cnt[bucket], 1u);
+    __syncthreads();
+    uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k <= S; k++) {
+            base[k] = run;
+            run += cnt[k];
+            off[k] = (uint16_t)run;  // off[0] = #big, off[s+1] = end of strip s
+        }
+    }
+    __syncthreads();
+    if (emit) a.recs[((size_t)b * a.nseg + seg) * SEG + base[bucket] + pos] = rec;
+}
+
+// ---- binned path, kernel 2: per (face, strip) LDS resolve + output ----------------------------------------
+// Block-wide exclusive scan of one value per thread (wave shuffles + one LDS hop).
+template <int BLOCK>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wtot, uint32_t& total) {
+    constexpr int NW = BLOCK / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(inc, d);
+        if (lane >= d) inc += n;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        uint32_t x = wtot[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+constexpr size_t resolve_scratch_bytes(int block) { return (size_t)(block + 1) * 4 + (size_t)block * 2 + 64 * 4 + 16; }
+
+// The bin's records are spread over the face's segments (a few per segment).  Walking segments one after the other
+// would serialise ~4 dependent memory round trips per segment; instead the per-segment counts are prefix-summed in
+// LDS and the threads take records from the flattened list, so all record loads of a bin are in flight together.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int tid = threadIdx.x;
+    const int bin = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bin / a.strips;
+    const int s = bin - b * a.strips;
+    const int r0 = s * a.rows;
+    const int r1 = min(a.H, r0 + a.rows);
+    const int W = a.W;
+    const int npix = (r1 - r0) * W;
+    // scratch behind the keys of a full strip (the launcher sizes the dynamic LDS for it)
+    uint32_t* pref = reinterpret_cast<uint32_t*>(keys + (size_t)a.rows * W);  // [BLOCK+1]
+    uint16_t* lo16 = reinterpret_cast<uint16_t*>(pref + BLOCK + 1);            // [BLOCK]
+    uint32_t* wtot = reinterpret_cast<uint32_t*>(lo16 + BLOCK);                      // [64] (BLOCK even: 4-byte aligned)
+    const unsigned long long KBG = bg_key();
+    for (int i = tid; i < npix; i += BLOCK) keys[i] = KBG;
+    const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.nver;
+    const float* __restrict__ vy = vx + a.nver;
+    const float* __restrict__ vz = vy + a.nver;
+
+    for (int c0 = 0; c0 < a.nseg; c0 += BLOCK) {
+        const int seg = c0 + tid;
+        uint32_t nbig = 0, lo = 0, hi = 0;
+        if (seg < a.nseg) {
+            const uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
+            nbig = off[0];
+            lo = off[s];
+            hi = off[s + 1];
+        }
+        const uint4* Rbase = a.recs + ((size_t)b * a.nseg + c0) * SEG;
+        // ---- this strip's small records ----
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan<BLOCK>(hi - lo, wtot, total);
+        pref[tid] = ex;
+        lo16[tid] = (uint16_t)lo;
+        if (tid == 0) pref[BLOCK] = total;
+        __syncthreads();  // also orders the key initialisation before the first atomics
+        if (a.dbg & 1) total = 0;
+        constexpr int RU = 4;  // records per lane per trip: all loads in flight before the first LDS atomic
+        for (uint32_t j0 = tid; j0 < total; j0 += BLOCK * RU) {
+            uint4 r[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const uint32_t j = j0 + u * BLOCK;
+                r[u] = make_uint4(0, 0, 0, 0);
+                if (j < total) {
+                    int k = 0;
+#pragma unroll
+                    for (int step = BLOCK >> 1; step > 0; step >>= 1)
+                        if (pref[k + step] <= j) k += step;  // largest k with pref[k] <= j
+                    r[u] = Rbase[(size_t)k * SEG + lo16[k] + (j - pref[k])];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const unsigned long long key = ((unsigned long long)r[u].y << 32) | r[u].x;
+                const int x0 = (int)(r[u].z & 0xFFFFu), y0 = (int)(r[u].z >> 16);
+                unsigned long long* row0 = keys + (size_t)(y0 - r0) * W + x0;
+                uint32_t m = r[u].w;  // 0 for the slots past the end
+                while (m) {
+                    const int bit = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    atomicMax(row0 + (bit >> 3) * W + (bit & 7), key);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the face's big / strip-straddling records (bucket 0 of every segment) ----
+        ex = block_exclusive_scan<BLOCK>(nbig, wtot, total);
+        pref[tid] = ex;
+        if (tid == 0) pref[BLOCK] = total;
+        __syncthreads();
+        if (a.dbg & 2) total = 0;
+        for (uint32_t j = tid; j < total; j += BLOCK) {
+            int k = 0;
+#pragma unroll
+            for (int step = BLOCK >> 1; step > 0; step >>= 1)
+                if (pref[k + step] <= j) k += step;
+            const uint4 r = Rbase[(size_t)k * SEG + (j - pref[k])];
+            const int t = (int)(0xFFFFFFFFu - r.x);
+            raster_triangle_into_strip(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, W, r0, r1, keys);
+        }
+        __syncthreads();
+    }
+    if (a.dbg & 4) return;
+    write_strip<BLOCK>(a, b, r0, npix, keys, vx, vy, vz);
 }
 
 // ---- backward: zeros + scatter-add of g/3 to the z row (render_depth_op.cc:345-363) -------------------------
@@ -203,39 +579,106 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
+static bool env_is(const char* name, const char* val) {
+    const char* v = getenv(name);
+    return v && strcmp(v, val) == 0;
+}
+
+namespace {
+struct RenderGeom {
+    int rows, strips, nseg;
+    size_t lds, recs_bytes, segoff_bytes, nrm_bytes;
+    bool binned_ok;
+};
+constexpr size_t kLdsMax = 160 * 1024;
+
+// bins: enough workgroups to cover the 256 CUs a few times over, never more rows than fit in LDS
+RenderGeom render_geom(int B, int ntri, int H, int W) {
+    RenderGeom g{};
+    const size_t row_bytes = (size_t)W * sizeof(unsigned long long);
+    int rows_max = row_bytes ? (int)((kLdsMax - fr::resolve_scratch_bytes(1024)) / row_bytes) : H;
+    if (rows_max < 1) rows_max = 0;  // a row does not fit: unsupported
+    int want_strips = B > 0 ? (512 + B - 1) / B : 1;
+    int rows = H > 0 ? (H + want_strips - 1) / want_strips : 1;
+    if (rows < fr::SMALL_H) rows = fr::SMALL_H;
+    int ov = env_int("FR_RENDER_ROWS", 0);  // tuning override
+    if (ov > 0) rows = ov;
+    if (rows > rows_max) rows = rows_max;
+    if (rows > H) rows = H;
+    if (rows < 1) rows = 1;
+    g.rows = rows;
+    g.strips = H > 0 ? (H + rows - 1) / rows : 0;
+    g.nseg = (ntri + fr::SEG - 1) / fr::SEG;
+    g.lds = (size_t)rows * row_bytes;
+    g.recs_bytes = (size_t)B * g.nseg * fr::SEG * sizeof(uint4);
+    g.segoff_bytes = (size_t)B * g.nseg * fr::OFF_STRIDE * sizeof(uint16_t);
+    g.nrm_bytes = (size_t)B * ntri * sizeof(float4);  // also the (maximum) size of the tritex table
+    g.binned_ok = rows_max >= 1 && g.strips <= fr::MAX_STRIPS && H <= 0xFFFF && W <= 0xFFFF &&
+                  (long long)B * g.nseg <= 0x7FFFFFFFll;
+    return g;
+}
+}  // namespace
+
+size_t fr_render_workspace_bytes_impl(int B, int ntri, int H, int W) {
+    if ((size_t)B * H * W == 0 || ntri == 0) return 0;
+    RenderGeom g = render_geom(B, ntri, H, W);
+    if (!g.binned_ok) return 0;
+    return g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes;
+}
 
 int fr_launch_render_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                              int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
-                             float* tri_ind, void* /*workspace*/, size_t /*ws_bytes*/, hipStream_t stream) {
+                             float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream) {
     using namespace fr;
     constexpr int BLOCK = 1024;
-    const size_t lds_max = 160 * 1024;
-    const size_t row_bytes = (size_t)W * sizeof(unsigned long long);
-    if (row_bytes > lds_max) return FR_ERR_UNSUPPORTED;
-    int rows_max = (int)(lds_max / row_bytes);
-    // bins: enough workgroups to cover the 256 CUs, never more rows than fit in LDS
-    int want_strips = (256 + B - 1) / B;
-    int rows = (H + want_strips - 1) / want_strips;
-    if (rows < 4) rows = H < 4 ? H : 4;
-    if (rows > rows_max) rows = rows_max;
-    int ov = env_int("FR_RENDER_ROWS", 0);  // tuning override
-    if (ov > 0) rows = ov > rows_max ? rows_max : ov;
-    if (rows > H) rows = H;
-    int strips = (H + rows - 1) / rows;
-    long long nbins = (long long)B * strips;
+    if ((size_t)W * sizeof(unsigned long long) > kLdsMax) return FR_ERR_UNSUPPORTED;
+    RenderGeom g = render_geom(B, ntri, H, W);
+    long long nbins = (long long)B * g.strips;
     if (nbins > 0x7FFFFFFFll) return FR_ERR_UNSUPPORTED;
 
     RenderArgs a;
     a.vertex = vertex; a.tri = tri; a.texture = texture;
     a.depth = depth; a.tex_img = tex_img; a.normal = normal; a.tri_ind = tri_ind;
     a.B = B; a.nver = nver; a.ntri = ntri; a.H = H; a.W = W;
-    a.rows = rows; a.strips = strips;
+    a.rows = g.rows; a.strips = g.strips;
     a.tex_stride = (tex_batch == 1) ? 0 : 3ll * nver;
-    size_t lds = (size_t)rows * row_bytes;
-    static unsigned char lds_ok[64];
-    if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_strip_kernel<BLOCK>), lds_ok) != hipSuccess)
-        return FR_ERR_LAUNCH;
-    hipLaunchKernelGGL(render_strip_kernel<BLOCK>, dim3((unsigned)nbins), dim3(BLOCK), lds, stream, a);
+    a.recs = nullptr; a.segoff = nullptr; a.nseg = g.nseg;
+    a.nrm_ws = nullptr; a.tritex_ws = nullptr;
+    a.dbg = env_int("FR_RENDER_DBG", 0);
+    a.wm1 = (float)(W - 1);
+    a.hm1 = (float)(H - 1);
+    a.rows_magic = g.rows > 1 ? (uint32_t)((0x100000000ull + (unsigned)g.rows - 1) / (unsigned)g.rows) : 0u;
+
+    const bool binned = g.binned_ok && ntri > 0 && !env_is("FR_RENDER_IMPL", "scan");
+    if (!binned) {
+        static unsigned char lds_ok[64];
+        if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_strip_kernel<BLOCK>), lds_ok) != hipSuccess)
+            return FR_ERR_LAUNCH;
+        hipLaunchKernelGGL(render_strip_kernel<BLOCK>, dim3((unsigned)nbins), dim3(BLOCK), g.lds, stream, a);
+        return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
+    }
+    if (ws_bytes < g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes || !workspace || ((uintptr_t)workspace & 15))
+        return FR_ERR_WORKSPACE;
+    char* wsp = reinterpret_cast<char*>(workspace);
+    a.recs = reinterpret_cast<uint4*>(wsp);
+    a.segoff = reinterpret_cast<uint16_t*>(wsp + g.recs_bytes);
+    a.nrm_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes);
+    a.tritex_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes + g.nrm_bytes);
+    if (!(a.dbg & 16))
+        hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(SEG), 0, stream, a);
+    if (env_int("FR_RESOLVE_BLOCK", 1024) == 512) {
+        static unsigned char ok512[64];
+        if (fr_allow_full_lds(reinterpret_cast<const void*>(&resolve_write_kernel<512>), ok512) != hipSuccess)
+            return FR_ERR_LAUNCH;
+        hipLaunchKernelGGL(resolve_write_kernel<512>, dim3((unsigned)nbins), dim3(512),
+                           g.lds + resolve_scratch_bytes(512), stream, a);
+    } else {
+        static unsigned char ok1024[64];
+        if (fr_allow_full_lds(reinterpret_cast<const void*>(&resolve_write_kernel<1024>), ok1024) != hipSuccess)
+            return FR_ERR_LAUNCH;
+        hipLaunchKernelGGL(resolve_write_kernel<1024>, dim3((unsigned)nbins), dim3(1024),
+                           g.lds + resolve_scratch_bytes(1024), stream, a);
+    }
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
