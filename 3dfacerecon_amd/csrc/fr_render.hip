@@ -666,7 +666,14 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
     a.tritex_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes + g.nrm_bytes);
     if (!(a.dbg & 16))
         hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(SEG), 0, stream, a);
-    if (env_int("FR_RESOLVE_BLOCK", 1024) == 512) {
+    const int rblk = env_int("FR_RESOLVE_BLOCK", 512);
+    if (rblk == 256) {
+        static unsigned char ok256[64];
+        if (fr_allow_full_lds(reinterpret_cast<const void*>(&resolve_write_kernel<256>), ok256) != hipSuccess)
+            return FR_ERR_LAUNCH;
+        hipLaunchKernelGGL(resolve_write_kernel<256>, dim3((unsigned)nbins), dim3(256),
+                           g.lds + resolve_scratch_bytes(256), stream, a);
+    } else if (rblk == 512) {
         static unsigned char ok512[64];
         if (fr_allow_full_lds(reinterpret_cast<const void*>(&resolve_write_kernel<512>), ok512) != hipSuccess)
             return FR_ERR_LAUNCH;
