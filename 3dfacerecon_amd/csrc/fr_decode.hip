@@ -24,7 +24,7 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int TILE_V = 16;      // vertices per wave tile (MFMA M)
 constexpr int KGROUP = 16;      // k values per packed group (4 k-steps of 4)
 constexpr int MAXB = 64;        // batch columns per pass (4 MFMA column blocks of 16)
-constexpr int DEC_WAVES = 16;   // waves per workgroup: one persistent workgroup per CU, 4 waves per SIMD
+constexpr int DEC_WAVES = 16;   // waves per workgroup: one persistent workgroup per CU, 4 waves per SIMD (<= 128 VGPRs)
 constexpr int DEC_BLOCK = DEC_WAVES * 64;
 
 __host__ __device__ inline int groups_of(int n) { return (n + KGROUP - 1) / KGROUP; }
@@ -95,11 +95,8 @@ __device__ __forceinline__ void mat3_mul(const double* A, const double* Bm, doub
         for (int j = 0; j < 3; j++)
             C[3 * i + j] = (A[3 * i + 0] * Bm[0 + j] + A[3 * i + 1] * Bm[3 + j]) + A[3 * i + 2] * Bm[6 + j];
 }
-__device__ void rotation_f64(float phi_f, float gamma_f, float theta_f, float* R9) {
-    double sp, cp, sy, cy, st, ct;
-    sincos((double)phi_f, &sp, &cp);
-    sincos((double)gamma_f, &sy, &cy);
-    sincos((double)theta_f, &st, &ct);
+__device__ __forceinline__ void rotation_from_sincos(double sp, double cp, double sy, double cy, double st, double ct,
+                                                     float* R9) {
     double Rp[9] = {1, 0, 0, 0, cp, sp, 0, -sp, cp};
     double Ry[9] = {cy, 0, -sy, 0, 1, 0, sy, 0, cy};
     double Rr[9] = {ct, st, 0, -st, ct, 0, 0, 0, 1};
@@ -132,10 +129,10 @@ __device__ __forceinline__ void mfma_step(float a, const typename BFrag<NBW>::ty
     for (int nb = 0; nb < NBW; nb++)
         acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bsel<NBW>(bq, nb), acc[nb], 0, 0, 0);
 }
-// Plg points at this lane's B fragment of the group's first k-step; consecutive k-steps are 64 float4 (1 KiB) apart.
+// Plg points at this lane's B fragment of the group's first k-step; consecutive k-steps are 64*NBW floats apart.
 template <int NBW>
 __device__ __forceinline__ typename BFrag<NBW>::type ldb(const float* Plg, int j) {
-    return *reinterpret_cast<const typename BFrag<NBW>::type*>(Plg + (size_t)j * 256);
+    return *reinterpret_cast<const typename BFrag<NBW>::type*>(Plg + (size_t)j * 64 * NBW);
 }
 template <int NBW>
 __device__ __forceinline__ void mfma_group3(float4 a0, float4 a1, float4 a2, const float* Plg, f32x4 (&acc0)[NBW],
@@ -162,50 +159,65 @@ __device__ __forceinline__ void mfma_group1(float4 a0, const float* Plg, f32x4 (
 // (NBW = 2): 6,652 items over 1,024 SIMDs balance to within 8 % of the MFMA floor, where whole tiles (3,326) would leave
 // a quarter of the matrix pipes idle in the last wave-round.  The two halves of a tile are taken by neighbouring waves
 // of the same workgroup at the same time, so the second read of the tile's A fragments is an L1/L2 hit.
+//
+// LDS image of the parameters (B operand), per half hf: P[hf][k][j][NBW] floats -- lane l of k-step s reads the NBW
+// consecutive floats at (s*64 + l)*NBW, i.e. one conflict-free ds_read_b32/b64 per k-step.
 template <int NBW>
 __global__ __launch_bounds__(DEC_BLOCK) void decode_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int GS = groups_of(a.ns), GE = groups_of(a.ne), G = GS + GE;
-    // LDS: Pl[(k*16 + j)*4 + nb] (k = padded coefficient index, j = column within block, nb = column block), Mt[64][12]
-    float* Mt = smem + (size_t)G * KGROUP * 16 * 4;
+    const int KP = G * KGROUP;                      // padded coefficient count
+    const size_t half_floats = (size_t)KP * 16 * NBW;
+    float* Mt = smem + (size_t)KP * 16 * 4;          // [64][12] after the 4 column blocks' parameters
+    double* SC = reinterpret_cast<double*>(Mt + 64 * 12);  // [64][3][2] sin/cos of the pose angles
     const int tid = threadIdx.x;
     const int nd = FR_N_POSE + a.ns + a.ne;
     const int nbatch = min(a.B - a.b0, 64);
 
-    // parameters -> LDS in B-fragment order: 16 threads per batch row (1024 = 64 x 16), each walks the row with stride
-    // 16; loads are unconditional (clamped) and batched so they pipeline; padding slots and absent rows are 0.
+    // parameters -> LDS in B-fragment order: TPR threads per batch row, each walks the row with stride
+    // TPR; loads are unconditional (clamped) and batched so they pipeline; padding slots and absent rows are 0.
     {
-        static_assert(DEC_BLOCK == 1024, "prologue assumes 64 rows x 16 threads");
-        const int bb = tid >> 4, sub = tid & 15;
+        constexpr int TPR = DEC_BLOCK / 64;  // threads per batch row
+        const int bb = tid / TPR, sub = tid - bb * TPR;
         const bool rowok = bb < nbatch;
         const float* prow = a.params + (size_t)(a.b0 + (rowok ? bb : 0)) * nd + FR_N_POSE;
-        float* dst = smem + (size_t)(bb & 15) * 4 + (bb >> 4);
+        const int nbk = bb >> 4;
+        float* dst = smem + (size_t)(nbk / NBW) * half_floats + (size_t)(bb & 15) * NBW + (nbk % NBW);
         const int KS = GS * KGROUP, KE = GE * KGROUP;
         if (a.ns > 0) {
-            for (int k0 = sub; k0 < KS; k0 += 128) {
+            for (int k0 = sub; k0 < KS; k0 += 8 * TPR) {
                 float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = prow[min(k0 + 16 * u, a.ns - 1)];
+                for (int u = 0; u < 8; u++) v[u] = prow[min(k0 + TPR * u, a.ns - 1)];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int k = k0 + 16 * u;
-                    if (k < KS) dst[(size_t)k * 64] = (rowok && k < a.ns) ? v[u] : 0.f;
+                    const int k = k0 + TPR * u;
+                    if (k < KS) dst[(size_t)k * 16 * NBW] = (rowok && k < a.ns) ? v[u] : 0.f;
                 }
             }
         }
         if (a.ne > 0) {
-            for (int k0 = sub; k0 < KE; k0 += 128) {
+            for (int k0 = sub; k0 < KE; k0 += 8 * TPR) {
                 float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = prow[a.ns + min(k0 + 16 * u, a.ne - 1)];
+                for (int u = 0; u < 8; u++) v[u] = prow[a.ns + min(k0 + TPR * u, a.ne - 1)];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int k = k0 + 16 * u;
-                    if (k < KE) dst[(size_t)(KS + k) * 64] = (rowok && k < a.ne) ? v[u] : 0.f;
+                    const int k = k0 + TPR * u;
+                    if (k < KE) dst[(size_t)(KS + k) * 16 * NBW] = (rowok && k < a.ne) ? v[u] : 0.f;
                 }
             }
         }
     }
+    // pose: the 192 float64 sincos evaluations are spread over 192 threads, then 64 threads assemble f*R and t
+    if (tid < 192 && !a.R_override) {
+        const int b = tid / 3, ang = tid - 3 * b;
+        double sn = 0.0, cs = 1.0;
+        if (b < nbatch) sincos((double)a.params[(size_t)(a.b0 + b) * nd + ang], &sn, &cs);
+        SC[(b * 3 + ang) * 2 + 0] = sn;
+        SC[(b * 3 + ang) * 2 + 1] = cs;
+    }
+    __syncthreads();
     if (tid < 64) {
         float m[12];
 #pragma unroll
@@ -217,7 +229,8 @@ __global__ __launch_bounds__(DEC_BLOCK) void decode_kernel(DecodeArgs a) {
 #pragma unroll
                 for (int i = 0; i < 9; i++) R[i] = a.R_override[(size_t)(a.b0 + tid) * 9 + i];
             } else {
-                rotation_f64(pr[0], pr[1], pr[2], R);
+                const double* sc = SC + tid * 6;
+                rotation_from_sincos(sc[0], sc[1], sc[2], sc[3], sc[4], sc[5], R);
             }
             float f = pr[6];
 #pragma unroll
@@ -234,22 +247,22 @@ __global__ __launch_bounds__(DEC_BLOCK) void decode_kernel(DecodeArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int tiles = tiles_of(a.N);
     const int N = a.N;
-    const int H2 = a.halves;
-    const long long items = (long long)tiles * H2;
-    // item = tile * halves + half; waves 2k and 2k+1 of a workgroup take neighbouring items (same tile when halves = 2)
-    for (long long it = (long long)blockIdx.x * DEC_WAVES + wave; it < items; it += (long long)gridDim.x * DEC_WAVES) {
-        const int tile = (int)(it / H2);
-        const int hf = (int)(it - (long long)tile * H2);
-        const float4* Ap = a.A + (size_t)tile * G * 3 * 64 + lane;  // group g, coordinate c at Ap[(g*3+c)*64]
-        const float* Pll = smem + (size_t)lane * 4 + hf * NBW;       // this lane's B fragment, k-step 0
-        f32x4 acc0[NBW], acc1[NBW], acc2[NBW];
+    // Work distribution: a tile's column-block halves go to neighbouring waves of one workgroup (they stream the same A
+    // fragments at the same time, so the second read is an L1/L2 hit); tiles are dealt round-robin over the
+    // workgroups so that the last, partial round leaves at most one extra tile per CU.
+    const int H2 = a.halves;              // 1 or 2
+    const int slots = DEC_WAVES / H2;     // tiles a workgroup works on at a time
+    const int slot = wave / H2;
+    const int hf = wave - slot * H2;
+    for (int tile = slot * gridDim.x + blockIdx.x; tile < tiles; tile += slots * gridDim.x) {
+        const float4* Ap = a.A + (size_t)tile * G * 3 * 64 + lane;   // group g, coordinate c at Ap[(g*3+c)*64]
+        const float* Pll = smem + (size_t)hf * half_floats + (size_t)lane * NBW;  // this lane's B fragment, k-step 0
+        f32x4 s0[NBW], s1[NBW], s2[NBW];
 #pragma unroll
-        for (int nb = 0; nb < NBW; nb++) acc0[nb] = acc1[nb] = acc2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NBW; nb++) s0[nb] = s1[nb] = s2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        // ---- S = pc_shape . alpha : fmaf chain over k from +0; A fragments double-buffered in registers so the
-        //      next group's 3 KiB are in flight while the current group's MFMAs issue ----
-        // two groups (6 KiB per wave, ~96 KiB per CU) are kept in flight: a round of the SIMD's four waves through
-        // one group is ~1.8 us at the clock the chip holds under MFMA load, about one HBM round trip.
+        // ---- S = pc_shape . alpha : fmaf chain over k from +0.  The A fragments of the next two groups (6 KiB per
+        //      wave, ~96 KiB per CU) are in flight while the current group's MFMAs issue ----
         float4 c0 = Ap[0], c1 = Ap[64], c2 = Ap[128];
         const int g1 = G > 1 ? 1 : 0;
         float4 d0 = Ap[(size_t)(g1 * 3 + 0) * 64], d1 = Ap[(size_t)(g1 * 3 + 1) * 64], d2 = Ap[(size_t)(g1 * 3 + 2) * 64];
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(DEC_BLOCK) void decode_kernel(DecodeArgs a) {
             const int gn = g + 2 < G ? g + 2 : G - 1;  // the last S groups prefetch the first E groups
             const float4 n0 = Ap[(size_t)(gn * 3 + 0) * 64], n1 = Ap[(size_t)(gn * 3 + 1) * 64],
                          n2 = Ap[(size_t)(gn * 3 + 2) * 64];
-            mfma_group3<NBW>(c0, c1, c2, Pll + (size_t)g * 1024, acc0, acc1, acc2);
+            mfma_group3<NBW>(c0, c1, c2, Pll + (size_t)g * 256 * NBW, s0, s1, s2);
             c0 = d0; c1 = d1; c2 = d2;
             d0 = n0; d1 = n1; d2 = n2;
         }
@@ -269,35 +282,35 @@ __global__ __launch_bounds__(DEC_BLOCK) void decode_kernel(DecodeArgs a) {
             const f32x4 m2 = *reinterpret_cast<const f32x4*>(mp + 2 * TILE_V);
 #pragma unroll
             for (int nb = 0; nb < NBW; nb++) {
-                acc0[nb] = m0 + acc0[nb];
-                acc1[nb] = m1 + acc1[nb];
-                acc2[nb] = m2 + acc2[nb];
+                s0[nb] = m0 + s0[nb];
+                s1[nb] = m1 + s1[nb];
+                s2[nb] = m2 + s2[nb];
             }
         }
         // ---- E = pc_exp . beta, one coordinate at a time (only NBW extra accumulators live), then
-        //      v = (mu + S) + E ----
+        //      v = (mu + S) + E.  Groups GS and GS+1 are already in c* / d*. ----
         {
             f32x4 e[NBW];
 #pragma unroll
             for (int nb = 0; nb < NBW; nb++) e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (GE > 0) mfma_group1<NBW>(c0, Pll + (size_t)GS * 1024, e);
-            if (GE > 1) mfma_group1<NBW>(d0, Pll + (size_t)(GS + 1) * 1024, e);
-            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 0) * 64], Pll + (size_t)g * 1024, e);
+            if (GE > 0) mfma_group1<NBW>(c0, Pll + (size_t)GS * 256 * NBW, e);
+            if (GE > 1) mfma_group1<NBW>(d0, Pll + (size_t)(GS + 1) * 256 * NBW, e);
+            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 0) * 64], Pll + (size_t)g * 256 * NBW, e);
 #pragma unroll
-            for (int nb = 0; nb < NBW; nb++) { acc0[nb] = acc0[nb] + e[nb]; e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            if (GE > 0) mfma_group1<NBW>(c1, Pll + (size_t)GS * 1024, e);
-            if (GE > 1) mfma_group1<NBW>(d1, Pll + (size_t)(GS + 1) * 1024, e);
-            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 1) * 64], Pll + (size_t)g * 1024, e);
+            for (int nb = 0; nb < NBW; nb++) { s0[nb] = s0[nb] + e[nb]; e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            if (GE > 0) mfma_group1<NBW>(c1, Pll + (size_t)GS * 256 * NBW, e);
+            if (GE > 1) mfma_group1<NBW>(d1, Pll + (size_t)(GS + 1) * 256 * NBW, e);
+            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 1) * 64], Pll + (size_t)g * 256 * NBW, e);
 #pragma unroll
-            for (int nb = 0; nb < NBW; nb++) { acc1[nb] = acc1[nb] + e[nb]; e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            if (GE > 0) mfma_group1<NBW>(c2, Pll + (size_t)GS * 1024, e);
-            if (GE > 1) mfma_group1<NBW>(d2, Pll + (size_t)(GS + 1) * 1024, e);
-            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 2) * 64], Pll + (size_t)g * 1024, e);
+            for (int nb = 0; nb < NBW; nb++) { s1[nb] = s1[nb] + e[nb]; e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            if (GE > 0) mfma_group1<NBW>(c2, Pll + (size_t)GS * 256 * NBW, e);
+            if (GE > 1) mfma_group1<NBW>(d2, Pll + (size_t)(GS + 1) * 256 * NBW, e);
+            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 2) * 64], Pll + (size_t)g * 256 * NBW, e);
 #pragma unroll
-            for (int nb = 0; nb < NBW; nb++) acc2[nb] = acc2[nb] + e[nb];
+            for (int nb = 0; nb < NBW; nb++) s2[nb] = s2[nb] + e[nb];
         }
         // ---- fused epilogue: 3x3 (f.R) transform, +t3d, y flip, store [B,3,N] ----
-        const int p0 = tile * TILE_V + 4 * (lane >> 4);  // first of this lane's 4 vertices
+        const int p0v = tile * TILE_V + 4 * (lane >> 4);  // first of this lane's 4 vertices
 #pragma unroll
         for (int nb = 0; nb < NBW; nb++) {
             const int bb = 16 * (hf * NBW + nb) + (lane & 15);
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(DEC_BLOCK) void decode_kernel(DecodeArgs a) {
             f32x4 px, py, pz;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float vx = acc0[nb][r], vy = acc1[nb][r], vz = acc2[nb][r];
+                const float vx = s0[nb][r], vy = s1[nb][r], vz = s2[nb][r];
                 const float qx = __builtin_fmaf(m[2], vz, __builtin_fmaf(m[1], vy, m[0] * vx)) + m[9];
                 const float qy = __builtin_fmaf(m[5], vz, __builtin_fmaf(m[4], vy, m[3] * vx)) + m[10];
                 const float qz = __builtin_fmaf(m[8], vz, __builtin_fmaf(m[7], vy, m[6] * vx)) + m[11];
@@ -314,17 +327,17 @@ __global__ __launch_bounds__(DEC_BLOCK) void decode_kernel(DecodeArgs a) {
                 py[r] = (a.im_size - qy) - 1.0f;  // network.py:168
                 pz[r] = qz;
             }
-            float* ox = a.out + ((size_t)(a.b0 + bb) * 3) * N + p0;
+            float* ox = a.out + ((size_t)(a.b0 + bb) * 3) * N + p0v;
             float* oy = ox + N;
             float* oz = oy + N;
-            if (p0 + 3 < N) {
+            if (p0v + 3 < N) {
                 *reinterpret_cast<f32x4u*>(ox) = px;
                 *reinterpret_cast<f32x4u*>(oy) = py;
                 *reinterpret_cast<f32x4u*>(oz) = pz;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    if (p0 + r < N) {
+                    if (p0v + r < N) {
                         ox[r] = px[r];
                         oy[r] = py[r];
                         oz[r] = pz[r];
@@ -384,7 +397,7 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
     if (B == 0 || N == 0) return FR_OK;
     size_t tiles = (size_t)tiles_of(N);
     size_t G = (size_t)groups_of(n_shape) + groups_of(n_exp);
-    size_t lds = G * KGROUP * 16 * sizeof(float4) + 64 * 12 * sizeof(float);
+    size_t lds = G * KGROUP * 16 * sizeof(float4) + 64 * 12 * sizeof(float) + 64 * 3 * 2 * sizeof(double);
     if (lds > 160 * 1024) return FR_ERR_UNSUPPORTED;
     DecodeArgs a;
     a.params = params;
@@ -400,8 +413,8 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
         const int nbt = (min(B - b0, MAXB) + 15) / 16;  // 16-column blocks in this pass (1..4)
         const int nbw = nbt == 1 ? 1 : 2;               // column blocks per work item
         a.halves = (nbt + nbw - 1) / nbw;
-        long long items = (long long)tiles * a.halves;
-        int grid = (int)min((long long)cus, (items + DEC_WAVES - 1) / DEC_WAVES);
+        const int slots = DEC_WAVES / a.halves;
+        int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
         int rc = nbw == 1 ? launch_decode_nbw<1>(a, lds, grid, stream) : launch_decode_nbw<2>(a, lds, grid, stream);
         if (rc != FR_OK) return rc;
     }

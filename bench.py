@@ -163,10 +163,10 @@ def main():
         ab = algorithmic_bytes(N, T, Kc, H, W, B)
         value = world * B * K / elapsed
         flops = 2.0 * 3 * N * Kc * B
-        roof_render = {"bound": "hbm", "kernel": "render_strip_kernel",
+        roof_render = {"bound": "hbm", "kernel": "fr_render_depth_forward = raster_emit_kernel + resolve_write_kernel",
                        "achieved": ab["render"] * B / (render_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "traffic": None, "avg_ms": render_ms}
-        roof_decode = {"bound": "mfma", "kernel": "decode_kernel",
+        roof_decode = {"bound": "mfma", "kernel": "fr_decode_3dmm = decode_kernel<2>",
                        "achieved": flops / (decode_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "traffic": None, "avg_ms": decode_ms,
                        "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9}

@@ -102,9 +102,45 @@ def gen_oracle_pins():
                         provenance="oracle/fr_oracle.c render forward/backward on synth.make_small_assets()")
 
 
+def config1_inputs():
+    """BASELINE.json configs[0]: one 200x200 face, fixed pose (beta = 1.0), shape/exp from RandomState(3456)."""
+    synth = importlib.import_module("3dfacerecon_amd.utils.synth")
+    A = synth.make_assets()
+    rs = np.random.RandomState(3456)
+    pose, shp, exp = synth.get_random_params(200, 199, 29, beta=1.0, rand=rs.rand)
+    P = np.concatenate([pose[:, 0], shp[:, 0], exp[:, 0]]).astype(np.float32)[None]
+    return A, P
+
+
+def gen_config1():
+    """Full-size face (53,215 vertices / 105,840 triangles) through the oracle, stored as hashes + sparse samples."""
+    import hashlib
+    import json
+    from oracle import oracle as O
+    A, P = config1_inputs()
+    V = O.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0)
+    d, t, n, ti = O.render_depth(V, A["tri"], A["vertex"][None], 200, 200)
+    img, ti_mex = O.zbuffer_mex(V[0].astype(np.float64), A["tri"].astype(np.float64), A["vertex"].astype(np.float64),
+                                np.zeros((200, 200, 3)))
+    ys, xs = np.nonzero(ti[0, :, :, 0] >= 0)
+    sel = np.linspace(0, len(ys) - 1, 64).astype(int)
+    out = {
+        "provenance": "oracle/fr_oracle.c on synth.make_assets(), params = get_random_params(200,199,29,beta=1.0) "
+                      "under RandomState(3456) (config 1)",
+        "pose": [float(x) for x in P[0, :7]],
+        "sha256": {k: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()
+                   for k, v in (("vertex_proj", V), ("depth", d), ("texture_image", t), ("normal", n), ("tri_ind", ti))},
+        "coverage": float((ti >= 0).mean()),
+        "mex_vs_op_tri_ind_mismatches": int((ti_mex != ti[0, :, :, 0]).sum()),
+        "samples": [[int(y), int(x), float(ti[0, y, x, 0]), float(d[0, y, x, 0])] for y, x in zip(ys[sel], xs[sel])],
+    }
+    json.dump(out, open(os.path.join(HERE, "config1_oracle.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     gen_rotation()
     gen_sampler()
     gen_oracle_pins()
+    gen_config1()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -44,3 +44,45 @@ def test_rendering_layer_wrapper(full_assets, synth):
     fg = n2 > 0.5
     assert fg.float().mean() > 0.2 and float((n2[fg] - 1).abs().max()) < 1e-3
     assert float(dimg.min()) >= float(np.float32(1e-6))
+
+
+def test_set_constraints_and_pose_parsing(small_assets):
+    """network.py:204-218, 253-263: value ranges of the 235-d vector and the pose slices."""
+    net = net_mod().FaceRecNet(mesh_data=small_assets, batch_size=4, im_size=200)
+    raw = torch.randn((4, 1, 1, net.ndim), device="cuda:0") * 3
+    p = net.set_constraints(raw)
+    assert tuple(p.shape) == (4, 1, 1, net.ndim)
+    q = p.reshape(4, net.ndim)
+    assert float(q[:, 0:3].abs().max()) <= 1.5
+    assert float(q[:, 3:5].min()) >= 0 and float(q[:, 3:5].max()) <= 200
+    assert float(q[:, 5].abs().max()) == 0.0
+    assert float(q[:, 6].min()) >= 0 and float(q[:, 6].max()) <= 1e-3
+    ns = net.ndim_shape
+    assert float(q[:, 7:7 + ns].min()) >= 0 and float(q[:, 7:7 + ns].max()) <= 1e4
+    assert float(q[:, 7 + ns:].abs().max()) <= 1.5
+    phi, gamma, theta, t3d, f = net.parse_pose_params(q[:, :7])
+    assert tuple(phi.shape) == (4, 1) and tuple(t3d.shape) == (4, 3) and tuple(f.shape) == (4, 1)
+    # host rotation helper == the oracle / reference fixture convention
+    R = net.rotation_matrix_batch(q[:, :3].cpu().numpy())
+    assert R.shape == (4, 3, 3) and R.dtype == np.float32
+    np.testing.assert_allclose(np.einsum("bij,bkj->bik", R, R), np.tile(np.eye(3), (4, 1, 1)), atol=1e-6)
+    # the constrained parameters decode + render without error
+    V = net.vertices_transform(p)
+    assert tuple(V.shape) == (4, 3, net.nvert) and bool(torch.isfinite(V).all())
+
+
+def test_plan_matches_operator_surface(full_assets, synth):
+    """DecodeRenderPlan (preallocated buffers, hipGraph) produces exactly what the op surface produces."""
+    pipe = __import__("importlib").import_module("3dfacerecon_amd.pipeline")
+    A = full_assets
+    net = net_mod().FaceRecNet(mesh_data=A, batch_size=3, im_size=200)
+    P = torch.as_tensor(synth.sample_params_batch(3, beta=0.7, seed=11), device="cuda:0")
+    V = net.vertices_transform(P)
+    want = ops().render_depth(V, net.tri, net.vertex_code, torch.zeros((3, 200, 200, 3), device="cuda:0"))
+    plan = pipe.DecodeRenderPlan(net, 3, 200, 200)
+    got = [o.clone() for o in plan.step(P)]
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    got2 = [o.clone() for o in plan.replay(P)]
+    for g, w in zip(got2, want):
+        assert torch.equal(g, w)
