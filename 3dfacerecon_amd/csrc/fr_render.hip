@@ -45,7 +45,7 @@ struct RenderArgs {
     // binned path workspace
     uint4* recs;           // [B][nseg][SEG] records
     uint16_t* segoff;      // [B][nseg][OFF_STRIDE] bucket offsets
-    float4* nrm_ws;        // [B][ntri]   un-normalised normal (xyz) of every emitting triangle
+    float4* recn;          // [B][nseg][SEG] un-normalised normal (xyz) of the record in the same slot of `recs`
     float4* tritex_ws;     // [tex_batch][ntri] per-triangle texture mean (one copy when the texture is shared)
     int nseg;
     float wm1, hm1;        // (float)(W-1), (float)(H-1)
@@ -53,7 +53,7 @@ struct RenderArgs {
     int dbg;               // diagnostic ablation mask (FR_RENDER_DBG), 0 in production
 };
 
-constexpr int SEG = 256;         // triangles (and record capacity) per segment
+constexpr int SEG = 512;         // triangles (and record capacity) per segment
 constexpr int OFF_STRIDE = 64;   // u16 offsets per segment (strips + 1 <= 64)
 constexpr int MAX_STRIPS = OFF_STRIDE - 1;
 constexpr int SMALL_W = 8, SMALL_H = 4;  // hit-mask window: bit = dy*8 + dx
@@ -68,10 +68,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // One triangle against one strip [r0, r1): the reference's per-triangle body (render_depth_op.cc:201-219, 263-316)
 // with the depth test replaced by the packed-key LDS max.
+// WINNER = false: resolve (LDS max).  WINNER = true: second pass -- the pixels whose resolved key is this triangle's
+// get `nval` stored to the normal plane `nplane` (strip-relative pixel index * 3).
+template <bool WINNER = false>
 __device__ __forceinline__ void raster_triangle_into_strip(int t, const float* __restrict__ tri,
                                                            const float* __restrict__ vx, const float* __restrict__ vy,
                                                            const float* __restrict__ vz, int nver, int ntri, int H,
-                                                           int W, int r0, int r1, unsigned long long* keys) {
+                                                           int W, int r0, int r1, unsigned long long* keys,
+                                                           float* nplane = nullptr, float4 nval = float4()) {
     // vertex ids: (int) truncation of float-stored indices, render_depth_op.cc:204-206
     int p1 = f2i_x86(tri[t]);
     int p2 = f2i_x86(tri[(size_t)ntri + t]);
@@ -96,7 +100,16 @@ __device__ __forceinline__ void raster_triangle_into_strip(int t, const float* _
     for (int y = ya; y <= yb; y++) {
         unsigned long long* row = keys + (size_t)(y - r0) * W;
         for (int x = x_min; x <= x_max; x++) {
-            if (point_in_tri(ts, x, y)) atomicMax(&row[x], key);
+            if (point_in_tri(ts, x, y)) {
+                if constexpr (!WINNER) {
+                    atomicMax(&row[x], key);
+                } else if (row[x] == key) {
+                    float* np = nplane + 3 * ((size_t)(y - r0) * W + x);
+                    np[0] = nval.x;
+                    np[1] = nval.y;
+                    np[2] = nval.z;
+                }
+            }
         }
     }
 }
@@ -156,21 +169,18 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
     float* nrm = a.normal + pix0 * 3;
     const bool vec_ok = ((npix & 3) == 0) && ((pix0 & 3) == 0) &&
                         ((((uintptr_t)a.depth | (uintptr_t)a.tri_ind | (uintptr_t)a.tex_img | (uintptr_t)a.normal) & 15) == 0);
-    if (a.nrm_ws != nullptr && ntri > 0 && !(a.dbg & 8)) {
-        // binned path: the emit kernel left each emitting triangle's normal and texture mean in the workspace as
-        // float4 tables indexed by triangle id, so a covered pixel costs two 16-byte loads.  One pixel per lane:
-        // neighbouring lanes hold neighbouring pixels -> neighbouring triangles -> shared cache lines.
-        const float4* __restrict__ nws = a.nrm_ws + (size_t)b * ntri;
+    if (a.recn != nullptr && ntri > 0 && !(a.dbg & 8)) {
+        // binned path: the normals of the covered pixels were already stored by the resolver's second pass; here
+        // depth / tri_ind / texture go out for every pixel and zeros for the background pixels' normals.  One pixel per
+        // lane: neighbouring lanes hold neighbouring pixels -> neighbouring triangles -> shared table lines.
         const float4* __restrict__ tws = a.tritex_ws + (a.tex_stride ? (size_t)b * ntri : 0);
         const unsigned long long KBG = bg_key();
-        // UNR pixels per lane per trip, all table loads issued before the first store: the tables were written by
-        // the emit kernel a moment ago and mostly come from HBM / Infinity Cache, so latency is paid once per trip.
         constexpr int UNR = 4;
         for (int i0 = tid; i0 < npix; i0 += BLOCK * UNR) {
             unsigned long long kk[UNR];
             bool cov[UNR];
             int t[UNR];
-            float4 nv[UNR], tv[UNR];
+            float4 tv[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
                 const int i = i0 + u * BLOCK;
@@ -179,10 +189,7 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
                 t[u] = cov[u] ? (int)(0xFFFFFFFFu - (uint32_t)kk[u]) : 0;
             }
 #pragma unroll
-            for (int u = 0; u < UNR; u++) {
-                nv[u] = nws[t[u]];
-                tv[u] = tws[t[u]];
-            }
+            for (int u = 0; u < UNR; u++) tv[u] = tws[t[u]];
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
                 const int i = i0 + u * BLOCK;
@@ -190,13 +197,15 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
                     dep[i] = cov[u] ? f32_unord((uint32_t)(kk[u] >> 32)) : bg_depth();
                     tin[i] = cov[u] ? (float)t[u] : -1.0f;
                     float* tp = txi + 3 * (size_t)i;
-                    float* np = nrm + 3 * (size_t)i;
                     tp[0] = cov[u] ? tv[u].x : 0.0f;
                     tp[1] = cov[u] ? tv[u].y : 0.0f;
                     tp[2] = cov[u] ? tv[u].z : 0.0f;
-                    np[0] = cov[u] ? nv[u].x : 0.0f;
-                    np[1] = cov[u] ? nv[u].y : 0.0f;
-                    np[2] = cov[u] ? nv[u].z : 0.0f;
+                    if (!cov[u]) {
+                        float* np = nrm + 3 * (size_t)i;
+                        np[0] = 0.0f;
+                        np[1] = 0.0f;
+                        np[2] = 0.0f;
+                    }
                 }
             }
         }
@@ -326,97 +335,168 @@ __device__ __forceinline__ bool id_ok(float f, int n, int& p) {
     return (f > -1.0f) && ((unsigned)p < (unsigned)n);
 }
 
-__global__ __launch_bounds__(SEG) void raster_emit_kernel(RenderArgs a) {
+// The kernel is VALU-bound (rocprof: SQ_ACTIVE_INST_VALU ~ 94 % of its duration), and about half of all triangles
+// are rejected by the bbox rule before any fp64 work.  So it runs in two phases.  Phase A: every thread takes TPT
+// triangles of the segment (all their loads in flight together), does the ids, the nine gathers and the bbox reject,
+// and survivors are compacted into an LDS queue.  Phase B runs the expensive part (depth, fp64 barycentric test,
+// normal, record emission) on DENSE waves -- about half as many wave-instructions -- and parks the records in LDS.
+// Phase C counting-sorts them by strip and writes them out.
+constexpr int EMIT_BLOCK = 256;
+constexpr int TPT = SEG / EMIT_BLOCK;  // triangles per thread in phase A
+
+__global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     __shared__ uint32_t cnt[OFF_STRIDE];
     __shared__ uint32_t base[OFF_STRIDE];
+    __shared__ uint32_t qn;
+    __shared__ float4 qa[SEG];   // phase A->B: x1 y1 x2 y2          phase B->C: the record
+    __shared__ float4 qb[SEG];   // phase A->B: x3 y3 z1 z2          phase B->C: the record's normal
+    __shared__ uint2 qd[SEG];    // .x: z3 (raw bits) in A->B, then bucket << 16 | pos (~0 = none) in B->C; .y: local index
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = lid / a.nseg;
     const int seg = lid - b * a.nseg;
-    const int t = seg * SEG + tid;
     const int S = a.strips;
     if (tid <= S) cnt[tid] = 0;
+    if (tid == 0) qn = 0;
     __syncthreads();
 
     const int nver = a.nver, ntri = a.ntri;
     const float* __restrict__ vx = a.vertex + (size_t)b * 3 * nver;
     const float* __restrict__ vy = vx + nver;
     const float* __restrict__ vz = vy + nver;
-    bool emit = false;
-    int bucket = 0;
-    uint4 rec = make_uint4(0, 0, 0, 0);
-    if (t < ntri) {
-        int p1, p2, p3;
-        const bool ok1 = id_ok(ld_off(a.tri, (uint32_t)t), nver, p1);
-        const bool ok2 = id_ok(ld_off(a.tri + ntri, (uint32_t)t), nver, p2);
-        const bool ok3 = id_ok(ld_off(a.tri + 2 * (size_t)ntri, (uint32_t)t), nver, p3);
-        if (a.dbg & 128) { p1 = t % nver; p2 = (t + 1) % nver; p3 = (t + 2) % nver; }
-        if (ok1 && ok2 && ok3) {  // else deviation 3: the reference would read out of bounds
-            // all nine gathers are independent once the ids are known: issue them together
-            const float x1 = ld_off(vx, p1), x2 = ld_off(vx, p2), x3 = ld_off(vx, p3);
-            const float y1 = ld_off(vy, p1), y2 = ld_off(vy, p2), y3 = ld_off(vy, p3);
-            const float z1 = ld_off(vz, p1), z2 = ld_off(vz, p2), z3 = ld_off(vz, p3);
+
+    // ---------------- phase A: ids, gathers, bbox reject ----------------
+    {
+        bool surv[TPT];
+        int p1[TPT], p2[TPT], p3[TPT];
+        float x1[TPT], x2[TPT], x3[TPT], y1[TPT], y2[TPT], y3[TPT], z1[TPT], z2[TPT], z3[TPT];
+        bool valid[TPT];
+#pragma unroll
+        for (int u = 0; u < TPT; u++) {
+            const int t = seg * SEG + u * EMIT_BLOCK + tid;
+            const uint32_t tt = (uint32_t)min(t, ntri - 1);
+            const bool ok1 = id_ok(ld_off(a.tri, tt), nver, p1[u]);
+            const bool ok2 = id_ok(ld_off(a.tri + ntri, tt), nver, p2[u]);
+            const bool ok3 = id_ok(ld_off(a.tri + 2 * (size_t)ntri, tt), nver, p3[u]);
+            // (ids outside [0,nver) -> deviation 3: the reference would read out of bounds)
+            valid[u] = (t < ntri) && ok1 && ok2 && ok3;
+            if (!valid[u]) p1[u] = p2[u] = p3[u] = 0;  // nver >= 1 here: safe dummy gathers
+        }
+#pragma unroll
+        for (int u = 0; u < TPT; u++) {
+            x1[u] = ld_off(vx, p1[u]); x2[u] = ld_off(vx, p2[u]); x3[u] = ld_off(vx, p3[u]);
+            y1[u] = ld_off(vy, p1[u]); y2[u] = ld_off(vy, p2[u]); y3[u] = ld_off(vy, p3[u]);
+            z1[u] = ld_off(vz, p1[u]); z2[u] = ld_off(vz, p2[u]); z3[u] = ld_off(vz, p3[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < TPT; u++) {
             // bbox = ceil(min) .. floor(max) per axis and the whole-triangle reject of render_depth_op.cc:276-283, in the
-            // float domain: a NaN coordinate makes PointInTri false for every pixel whatever the bbox (all dot products
-            // turn NaN), so the NaN-ignoring v_min3/v_max3 are equivalent to the reference's macros here; the negated
+            // float domain.  A NaN coordinate makes PointInTri false for every pixel whatever the bbox (all dot products
+            // turn NaN), so the NaN-ignoring v_min3/v_max3 are equivalent to the reference's macros here; the
             // comparisons reject NaN / +-inf / out-of-int-range bounds exactly where (int) gives INT_MIN on x86.
-            const float fx0 = ceilf(fminf(fminf(x1, x2), x3)), fx1 = floorf(fmaxf(fmaxf(x1, x2), x3));
-            const float fy0 = ceilf(fminf(fminf(y1, y2), y3)), fy1 = floorf(fmaxf(fmaxf(y1, y2), y3));
-            const bool xy_nan = (x1 != x1) || (x2 != x2) || (x3 != x3) || (y1 != y1) || (y2 != y2) || (y3 != y3);
-            bool rej = !(fx0 >= 0.0f) || !(fy0 >= 0.0f) || !(fx1 <= a.wm1) || !(fy1 <= a.hm1) || (fx1 < fx0) ||
-                       (fy1 < fy0) || xy_nan;
-            if (a.dbg & 32) { asm volatile("" ::"v"(z1), "v"(z2), "v"(z3)); rej = true; }
-            float h = ((z1 + z2) + z3) / 3.0f;  // fp32 centroid depth, :217
-            h = h + 0.0f;                        // -0 -> +0
-            if (!rej && (h > bg_depth())) {      // NaN or <= background never passes 'depth < h' (:295)
-                const int x_min = (int)fx0, x_max = (int)fx1, y_min = (int)fy0, y_max = (int)fy1;
-                const unsigned long long key = make_key(h, t);
-                rec.x = (uint32_t)key;
-                rec.y = (uint32_t)(key >> 32);
-                rec.z = (uint32_t)x_min | ((uint32_t)y_min << 16);
-                // strip of the first / last row: y / rows through the exact 2^32 reciprocal (y, rows < 2^16)
-                const int s0 = a.rows_magic ? (int)__umulhi((uint32_t)y_min, a.rows_magic) : y_min;
-                const int s1 = a.rows_magic ? (int)__umulhi((uint32_t)y_max, a.rows_magic) : y_max;
-                if (x_max - x_min < SMALL_W && y_max - y_min < SMALL_H && s0 == s1) {
-                    const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
-                    uint32_t m = 0;
-                    for (int y = y_min; y <= y_max; y++)
-                        for (int x = x_min; x <= x_max; x++)
-                            if (point_in_tri(ts, x, y)) m |= 1u << ((y - y_min) * SMALL_W + (x - x_min));
-                    rec.w = m;
-                    emit = (m != 0);
-                    bucket = 1 + s0;
-                } else {
-                    rec.w = 0;
-                    emit = true;
-                    bucket = 0;
-                }
-                if (emit && !(a.dbg & 64)) {
-                    // un-normalised normal (p1-p2) x (p1-p3): fp32 differences, fp64 products without FMA, one
-                    // rounding (render_depth_op.cc:227-236, 308) -- computed here, where the vertices are in registers
-                    double ax = (double)(x1 - x2), ay = (double)(y1 - y2), az = (double)(z1 - z2);
-                    double bx = (double)(x1 - x3), by = (double)(y1 - y3), bz = (double)(z1 - z3);
-                    a.nrm_ws[(size_t)b * ntri + t] = make_float4((float)(ay * bz - az * by), (float)(az * bx - ax * bz),
-                                                                 (float)(ax * by - ay * bx), 0.0f);
-                }
-            }
-            // per-triangle texture mean ((t1+t2)+t3)/3 in fp32 (render_depth_op.cc:223): per face when every face has
-            // its own texture, otherwise once (by face 0's workgroups) for all faces
-            if (a.tex_stride ? emit : (b == 0)) {
-                const float* __restrict__ tex = a.texture + (size_t)b * a.tex_stride;
+            const float fx0 = ceilf(fminf(fminf(x1[u], x2[u]), x3[u])), fx1 = floorf(fmaxf(fmaxf(x1[u], x2[u]), x3[u]));
+            const float fy0 = ceilf(fminf(fminf(y1[u], y2[u]), y3[u])), fy1 = floorf(fmaxf(fmaxf(y1[u], y2[u]), y3[u]));
+            surv[u] = valid[u] && (fx0 >= 0.0f) && (fy0 >= 0.0f) && (fx1 <= a.wm1) && (fy1 <= a.hm1) && !(fx1 < fx0) &&
+                      !(fy1 < fy0);
+            // per-triangle texture mean ((t1+t2)+t3)/3 in fp32 (render_depth_op.cc:223) when the texture is shared by the
+            // batch: computed once, by face 0's workgroups, for every valid triangle
+            if (a.tex_stride == 0 && b == 0 && valid[u]) {
                 float tm[3];
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    const float* tj = tex + (size_t)j * nver;
-                    tm[j] = ((ld_off(tj, p1) + ld_off(tj, p2)) + ld_off(tj, p3)) / 3.0f;
+                    const float* tj = a.texture + (size_t)j * nver;
+                    tm[j] = ((ld_off(tj, p1[u]) + ld_off(tj, p2[u])) + ld_off(tj, p3[u])) / 3.0f;
                 }
-                a.tritex_ws[(size_t)(a.tex_stride ? b : 0) * ntri + t] = make_float4(tm[0], tm[1], tm[2], 0.0f);
+                a.tritex_ws[seg * SEG + u * EMIT_BLOCK + tid] = make_float4(tm[0], tm[1], tm[2], 0.0f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPT; u++) {
+            const unsigned long long m = __ballot(surv[u]);
+            uint32_t wbase = 0;
+            if (lane == 0 && m) wbase = atomicAdd(&qn, (uint32_t)__popcll(m));
+            wbase = __shfl(wbase, 0);
+            if (surv[u]) {
+                const uint32_t slot = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                qa[slot] = make_float4(x1[u], y1[u], x2[u], y2[u]);
+                qb[slot] = make_float4(x3[u], y3[u], z1[u], z2[u]);
+                qd[slot] = make_uint2(__float_as_uint(z3[u]), (uint32_t)(u * EMIT_BLOCK + tid));
             }
         }
     }
-    uint32_t pos = 0;
-    if (emit) pos = atomicAdd(&cnt[bucket], 1u);
     __syncthreads();
+
+    // ---------------- phase B: dense lanes, one surviving triangle each ----------------
+    const int nq = (int)qn;
+    for (int sl = tid; sl < nq; sl += EMIT_BLOCK) {
+        const float4 A4 = qa[sl], B4 = qb[sl];
+        const uint2 D2 = qd[sl];
+        const float x1 = A4.x, y1 = A4.y, x2 = A4.z, y2 = A4.w, x3 = B4.x, y3 = B4.y;
+        const float z1 = B4.z, z2 = B4.w, z3 = __uint_as_float(D2.x);
+        bool emit = false;
+        int bucket = 0;
+        uint4 rec = make_uint4(0, 0, 0, 0);
+        float4 nrm4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float h = ((z1 + z2) + z3) / 3.0f;  // fp32 centroid depth, :217
+        h = h + 0.0f;                        // -0 -> +0
+        const int t = seg * SEG + (int)D2.y;
+        if (h > bg_depth()) {                // NaN or <= background never passes 'depth < h' (:295)
+            const int x_min = (int)ceilf(fminf(fminf(x1, x2), x3)), x_max = (int)floorf(fmaxf(fmaxf(x1, x2), x3));
+            const int y_min = (int)ceilf(fminf(fminf(y1, y2), y3)), y_max = (int)floorf(fmaxf(fmaxf(y1, y2), y3));
+            const unsigned long long key = make_key(h, t);
+            rec.x = (uint32_t)key;
+            rec.y = (uint32_t)(key >> 32);
+            rec.z = (uint32_t)x_min | ((uint32_t)y_min << 16);
+            // strip of the first / last row: y / rows through the exact 2^32 reciprocal (y, rows < 2^16)
+            const int s0 = a.rows_magic ? (int)__umulhi((uint32_t)y_min, a.rows_magic) : y_min;
+            const int s1 = a.rows_magic ? (int)__umulhi((uint32_t)y_max, a.rows_magic) : y_max;
+            if (x_max - x_min < SMALL_W && y_max - y_min < SMALL_H && s0 == s1) {
+                const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
+                uint32_t m = 0;
+                for (int y = y_min; y <= y_max; y++)
+                    for (int x = x_min; x <= x_max; x++)
+                        if (point_in_tri(ts, x, y)) m |= 1u << ((y - y_min) * SMALL_W + (x - x_min));
+                rec.w = m;
+                emit = (m != 0);
+                bucket = 1 + s0;
+            } else {
+                rec.w = 0;
+                emit = true;
+                bucket = 0;
+            }
+            if (emit) {
+                // un-normalised normal (p1-p2) x (p1-p3): fp32 differences, fp64 products without FMA, one rounding
+                // (render_depth_op.cc:227-236, 308) -- computed here, where the vertices are at hand
+                double ax = (double)(x1 - x2), ay = (double)(y1 - y2), az = (double)(z1 - z2);
+                double bx = (double)(x1 - x3), by = (double)(y1 - y3), bz = (double)(z1 - z3);
+                nrm4 = make_float4((float)(ay * bz - az * by), (float)(az * bx - ax * bz), (float)(ax * by - ay * bx), 0.0f);
+                if (a.tex_stride) {  // every face has its own texture: mean per emitting (face, triangle)
+                    const float* __restrict__ tex = a.texture + (size_t)b * a.tex_stride;
+                    const int p1 = (int)ld_off(a.tri, (uint32_t)t), p2 = (int)ld_off(a.tri + ntri, (uint32_t)t),
+                              p3 = (int)ld_off(a.tri + 2 * (size_t)ntri, (uint32_t)t);  // valid: checked in phase A
+                    float tm[3];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const float* tj = tex + (size_t)j * nver;
+                        tm[j] = ((ld_off(tj, p1) + ld_off(tj, p2)) + ld_off(tj, p3)) / 3.0f;
+                    }
+                    a.tritex_ws[(size_t)b * ntri + t] = make_float4(tm[0], tm[1], tm[2], 0.0f);
+                }
+            }
+        }
+        uint32_t tag = 0xFFFFFFFFu;
+        if (emit) {
+            const uint32_t pos = atomicAdd(&cnt[bucket], 1u);
+            tag = ((uint32_t)bucket << 16) | pos;
+            qa[sl] = make_float4(__uint_as_float(rec.x), __uint_as_float(rec.y), __uint_as_float(rec.z),
+                                 __uint_as_float(rec.w));
+            qb[sl] = nrm4;
+        }
+        qd[sl].x = tag;
+    }
+    __syncthreads();
+    // ---------------- phase C: bucket offsets, records out ----------------
     uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
     if (tid == 0) {
         uint32_t run = 0;
@@ -427,7 +507,17 @@ __global__ __launch_bounds__(SEG) void raster_emit_kernel(RenderArgs a) {
         }
     }
     __syncthreads();
-    if (emit) a.recs[((size_t)b * a.nseg + seg) * SEG + base[bucket] + pos] = rec;
+    uint4* R = a.recs + ((size_t)b * a.nseg + seg) * SEG;
+    float4* Rn = a.recn + ((size_t)b * a.nseg + seg) * SEG;
+    for (int sl = tid; sl < nq; sl += EMIT_BLOCK) {
+        const uint32_t tag = qd[sl].x;
+        if (tag != 0xFFFFFFFFu) {
+            const float4 r = qa[sl];
+            const uint32_t slot = base[tag >> 16] + (tag & 0xFFFFu);
+            R[slot] = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
+            Rn[slot] = qb[sl];
+        }
+    }
 }
 
 // ---- binned path, kernel 2: per (face, strip) LDS resolve + output ----------------------------------------
@@ -475,76 +565,109 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     // scratch behind the keys of a full strip (the launcher sizes the dynamic LDS for it)
     uint32_t* pref = reinterpret_cast<uint32_t*>(keys + (size_t)a.rows * W);  // [BLOCK+1]
     uint16_t* lo16 = reinterpret_cast<uint16_t*>(pref + BLOCK + 1);            // [BLOCK]
-    uint32_t* wtot = reinterpret_cast<uint32_t*>(lo16 + BLOCK);                      // [64] (BLOCK even: 4-byte aligned)
+    uint32_t* wtot = reinterpret_cast<uint32_t*>(lo16 + BLOCK);                 // [64] (BLOCK even: 4-byte aligned)
     const unsigned long long KBG = bg_key();
     for (int i = tid; i < npix; i += BLOCK) keys[i] = KBG;
     const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.nver;
     const float* __restrict__ vy = vx + a.nver;
     const float* __restrict__ vz = vy + a.nver;
+    float* nplane = a.normal + (((size_t)b * a.H + r0) * W) * 3;  // the strip's slice of the normal plane
+    constexpr int RU = 4;  // records per lane per trip: all loads in flight before the first LDS operation
 
-    for (int c0 = 0; c0 < a.nseg; c0 += BLOCK) {
-        const int seg = c0 + tid;
-        uint32_t nbig = 0, lo = 0, hi = 0;
-        if (seg < a.nseg) {
-            const uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
-            nbig = off[0];
-            lo = off[s];
-            hi = off[s + 1];
-        }
-        const uint4* Rbase = a.recs + ((size_t)b * a.nseg + c0) * SEG;
-        // ---- this strip's small records ----
-        uint32_t total;
-        uint32_t ex = block_exclusive_scan<BLOCK>(hi - lo, wtot, total);
-        pref[tid] = ex;
-        lo16[tid] = (uint16_t)lo;
-        if (tid == 0) pref[BLOCK] = total;
-        __syncthreads();  // also orders the key initialisation before the first atomics
-        if (a.dbg & 1) total = 0;
-        constexpr int RU = 4;  // records per lane per trip: all loads in flight before the first LDS atomic
-        for (uint32_t j0 = tid; j0 < total; j0 += BLOCK * RU) {
-            uint4 r[RU];
+    // pass 0: z-resolve -- every hit becomes one ds_max_u64.  pass 1: the winners are known; each record looks its hit
+    // pixels up again and, where its key won, stores its normal (kept in the record's companion slot) to the normal
+    // plane.  The second read of the records is an L1/L2 hit.
+    for (int pass = 0; pass < 2; pass++) {
+        for (int c0 = 0; c0 < a.nseg; c0 += BLOCK) {
+            const int seg = c0 + tid;
+            uint32_t nbig = 0, lo = 0, hi = 0;
+            if (seg < a.nseg) {
+                const uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
+                nbig = off[0];
+                lo = off[s];
+                hi = off[s + 1];
+            }
+            const uint4* Rbase = a.recs + ((size_t)b * a.nseg + c0) * SEG;
+            const float4* Nbase = a.recn + ((size_t)b * a.nseg + c0) * SEG;
+            // ---- this strip's small records ----
+            uint32_t total;
+            uint32_t ex = block_exclusive_scan<BLOCK>(hi - lo, wtot, total);
+            pref[tid] = ex;
+            lo16[tid] = (uint16_t)lo;
+            if (tid == 0) pref[BLOCK] = total;
+            __syncthreads();  // also orders the key initialisation before the first atomics
+            for (uint32_t j0 = tid; j0 < total; j0 += BLOCK * RU) {
+                uint4 r[RU];
+                uint32_t slot[RU];
 #pragma unroll
-            for (int u = 0; u < RU; u++) {
-                const uint32_t j = j0 + u * BLOCK;
-                r[u] = make_uint4(0, 0, 0, 0);
-                if (j < total) {
-                    int k = 0;
+                for (int u = 0; u < RU; u++) {
+                    const uint32_t j = j0 + u * BLOCK;
+                    r[u] = make_uint4(0, 0, 0, 0);
+                    slot[u] = 0;
+                    if (j < total) {
+                        int k = 0;
 #pragma unroll
-                    for (int step = BLOCK >> 1; step > 0; step >>= 1)
-                        if (pref[k + step] <= j) k += step;  // largest k with pref[k] <= j
-                    r[u] = Rbase[(size_t)k * SEG + lo16[k] + (j - pref[k])];
+                        for (int step = BLOCK >> 1; step > 0; step >>= 1)
+                            if (pref[k + step] <= j) k += step;  // largest k with pref[k] <= j
+                        slot[u] = (uint32_t)k * SEG + lo16[k] + (j - pref[k]);
+                        r[u] = Rbase[slot[u]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    const unsigned long long key = ((unsigned long long)r[u].y << 32) | r[u].x;
+                    const int x0 = (int)(r[u].z & 0xFFFFu), y0 = (int)(r[u].z >> 16);
+                    const size_t p0 = (size_t)(y0 - r0) * W + x0;
+                    uint32_t m = r[u].w;  // 0 for the slots past the end
+                    if (pass == 0) {
+                        while (m) {
+                            const int bit = __ffs((int)m) - 1;
+                            m &= m - 1;
+                            atomicMax(keys + p0 + (bit >> 3) * W + (bit & 7), key);
+                        }
+                    } else {
+                        uint32_t won = 0;
+                        while (m) {
+                            const int bit = __ffs((int)m) - 1;
+                            m &= m - 1;
+                            if (keys[p0 + (bit >> 3) * W + (bit & 7)] == key) won |= 1u << bit;
+                        }
+                        if (won) {
+                            const float4 nv = Nbase[slot[u]];
+                            while (won) {
+                                const int bit = __ffs((int)won) - 1;
+                                won &= won - 1;
+                                float* np = nplane + 3 * (p0 + (bit >> 3) * W + (bit & 7));
+                                np[0] = nv.x;
+                                np[1] = nv.y;
+                                np[2] = nv.z;
+                            }
+                        }
+                    }
                 }
             }
+            __syncthreads();
+            // ---- the face's big / strip-straddling records (bucket 0 of every segment) ----
+            ex = block_exclusive_scan<BLOCK>(nbig, wtot, total);
+            pref[tid] = ex;
+            if (tid == 0) pref[BLOCK] = total;
+            __syncthreads();
+            for (uint32_t j = tid; j < total; j += BLOCK) {
+                int k = 0;
 #pragma unroll
-            for (int u = 0; u < RU; u++) {
-                const unsigned long long key = ((unsigned long long)r[u].y << 32) | r[u].x;
-                const int x0 = (int)(r[u].z & 0xFFFFu), y0 = (int)(r[u].z >> 16);
-                unsigned long long* row0 = keys + (size_t)(y0 - r0) * W + x0;
-                uint32_t m = r[u].w;  // 0 for the slots past the end
-                while (m) {
-                    const int bit = __ffs((int)m) - 1;
-                    m &= m - 1;
-                    atomicMax(row0 + (bit >> 3) * W + (bit & 7), key);
-                }
+                for (int step = BLOCK >> 1; step > 0; step >>= 1)
+                    if (pref[k + step] <= j) k += step;
+                const uint32_t slot = (uint32_t)k * SEG + (j - pref[k]);
+                const uint4 r = Rbase[slot];
+                const int t = (int)(0xFFFFFFFFu - r.x);
+                if (pass == 0)
+                    raster_triangle_into_strip<false>(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, W, r0, r1, keys);
+                else
+                    raster_triangle_into_strip<true>(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, W, r0, r1, keys, nplane,
+                                                     Nbase[slot]);
             }
+            __syncthreads();
         }
-        __syncthreads();
-        // ---- the face's big / strip-straddling records (bucket 0 of every segment) ----
-        ex = block_exclusive_scan<BLOCK>(nbig, wtot, total);
-        pref[tid] = ex;
-        if (tid == 0) pref[BLOCK] = total;
-        __syncthreads();
-        if (a.dbg & 2) total = 0;
-        for (uint32_t j = tid; j < total; j += BLOCK) {
-            int k = 0;
-#pragma unroll
-            for (int step = BLOCK >> 1; step > 0; step >>= 1)
-                if (pref[k + step] <= j) k += step;
-            const uint4 r = Rbase[(size_t)k * SEG + (j - pref[k])];
-            const int t = (int)(0xFFFFFFFFu - r.x);
-            raster_triangle_into_strip(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, W, r0, r1, keys);
-        }
-        __syncthreads();
     }
     if (a.dbg & 4) return;
     write_strip<BLOCK>(a, b, r0, npix, keys, vx, vy, vz);
@@ -612,7 +735,7 @@ RenderGeom render_geom(int B, int ntri, int H, int W) {
     g.lds = (size_t)rows * row_bytes;
     g.recs_bytes = (size_t)B * g.nseg * fr::SEG * sizeof(uint4);
     g.segoff_bytes = (size_t)B * g.nseg * fr::OFF_STRIDE * sizeof(uint16_t);
-    g.nrm_bytes = (size_t)B * ntri * sizeof(float4);  // also the (maximum) size of the tritex table
+    g.nrm_bytes = (size_t)B * g.nseg * fr::SEG * sizeof(float4);  // per-record normals; also bounds the tritex table
     g.binned_ok = rows_max >= 1 && g.strips <= fr::MAX_STRIPS && H <= 0xFFFF && W <= 0xFFFF &&
                   (long long)B * g.nseg <= 0x7FFFFFFFll;
     return g;
@@ -631,6 +754,7 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
                              float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream) {
     using namespace fr;
     constexpr int BLOCK = 1024;
+    if (nver == 0) ntri = 0;  // no vertex can be valid: every triangle is skipped, the planes are pure background
     if ((size_t)W * sizeof(unsigned long long) > kLdsMax) return FR_ERR_UNSUPPORTED;
     RenderGeom g = render_geom(B, ntri, H, W);
     long long nbins = (long long)B * g.strips;
@@ -643,7 +767,7 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
     a.rows = g.rows; a.strips = g.strips;
     a.tex_stride = (tex_batch == 1) ? 0 : 3ll * nver;
     a.recs = nullptr; a.segoff = nullptr; a.nseg = g.nseg;
-    a.nrm_ws = nullptr; a.tritex_ws = nullptr;
+    a.recn = nullptr; a.tritex_ws = nullptr;
     a.dbg = env_int("FR_RENDER_DBG", 0);
     a.wm1 = (float)(W - 1);
     a.hm1 = (float)(H - 1);
@@ -662,10 +786,10 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
     char* wsp = reinterpret_cast<char*>(workspace);
     a.recs = reinterpret_cast<uint4*>(wsp);
     a.segoff = reinterpret_cast<uint16_t*>(wsp + g.recs_bytes);
-    a.nrm_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes);
+    a.recn = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes);
     a.tritex_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes + g.nrm_bytes);
     if (!(a.dbg & 16))
-        hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(SEG), 0, stream, a);
+        hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
     const int rblk = env_int("FR_RESOLVE_BLOCK", 512);
     if (rblk == 256) {
         static unsigned char ok256[64];

@@ -52,10 +52,10 @@ def test_validation_codes_without_gpu():
     assert L.fr_decode_3dmm(nul, one, nul, 2, 10, 2, 2, 200.0, one, nul) == -1
     assert L.fr_decode_3dmm(nul, nul, nul, 0, 10, 2, 2, 200.0, nul, nul) == 0
     # binned rasteriser workspace: 16-byte hit records (one slot per triangle) + 64 u16 bucket offsets per segment
-    # + per-(face, triangle) normal table + texture-mean table (float4 each)
-    nseg = (105840 + 255) // 256
+    # + per-record normals (float4, same slots) + texture-mean table (float4 per triangle, same bound)
+    nseg = (105840 + 511) // 512
     assert L.fr_render_depth_workspace_bytes(64, 53215, 105840, 200, 200) == \
-        64 * nseg * (256 * 16 + 64 * 2) + 2 * 64 * 105840 * 16
+        64 * nseg * (512 * 16 + 64 * 2) + 2 * 64 * nseg * 512 * 16
     assert L.fr_render_depth_workspace_bytes(0, 5, 5, 8, 8) == 0
     # workspace too small
     assert L.fr_render_depth_forward(one, one, one, 1, 3, 1, 4, 4, 3, 1, one, one, one, one, nul, 0, nul) == -2
