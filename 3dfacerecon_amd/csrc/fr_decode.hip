@@ -24,8 +24,8 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int TILE_V = 16;      // vertices per wave tile (MFMA M)
 constexpr int KGROUP = 16;      // k values per packed group (4 k-steps of 4)
 constexpr int MAXB = 64;        // batch columns per pass (4 MFMA column blocks of 16)
-constexpr int DEC_WAVES = 16;   // waves per workgroup: one persistent workgroup per CU, 4 waves per SIMD (<= 128 VGPRs)
-constexpr int DEC_BLOCK = DEC_WAVES * 64;
+// waves per persistent workgroup (one per CU): 16 (4 per SIMD, <= 128 VGPRs) for 32-column work items, 12 (3 per
+// SIMD, <= 168 VGPRs) for 64-column work items
 
 __host__ __device__ inline int groups_of(int n) { return (n + KGROUP - 1) / KGROUP; }
 __host__ __device__ inline int tiles_of(int N) { return (N + TILE_V - 1) / TILE_V; }
@@ -162,8 +162,9 @@ __device__ __forceinline__ void mfma_group1(float4 a0, const float* Plg, f32x4 (
 //
 // LDS image of the parameters (B operand), per half hf: P[hf][k][j][NBW] floats -- lane l of k-step s reads the NBW
 // consecutive floats at (s*64 + l)*NBW, i.e. one conflict-free ds_read_b32/b64 per k-step.
-template <int NBW>
-__global__ __launch_bounds__(DEC_BLOCK) void decode_kernel(DecodeArgs a) {
+template <int NBW, int DEC_WAVES>
+__global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
+    constexpr int DEC_BLOCK = DEC_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int GS = groups_of(a.ns), GE = groups_of(a.ne), G = GS + GE;
     const int KP = G * KGROUP;                      // padded coefficient count
@@ -382,12 +383,14 @@ static int device_cu_count() {
     return cus[dev];
 }
 
-template <int NBW>
-static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int grid, hipStream_t stream) {
+template <int NBW, int WAVES>
+static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int cus, size_t tiles, hipStream_t stream) {
     static unsigned char lds_ok[64];
-    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_kernel<NBW>), lds_ok) != hipSuccess)
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_kernel<NBW, WAVES>), lds_ok) != hipSuccess)
         return FR_ERR_LAUNCH;
-    hipLaunchKernelGGL(fr::decode_kernel<NBW>, dim3(grid), dim3(fr::DEC_BLOCK), lds, stream, a);
+    const int slots = WAVES / a.halves;
+    const int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
+    hipLaunchKernelGGL((fr::decode_kernel<NBW, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
@@ -411,11 +414,13 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
     for (int b0 = 0; b0 < B; b0 += MAXB) {
         a.b0 = b0;
         const int nbt = (min(B - b0, MAXB) + 15) / 16;  // 16-column blocks in this pass (1..4)
-        const int nbw = nbt == 1 ? 1 : 2;               // column blocks per work item
+        static const int nbw_env = getenv("FR_DECODE_NBW") ? atoi(getenv("FR_DECODE_NBW")) : 0;
+        int nbw = nbt == 1 ? 1 : 2;                     // column blocks per work item
+        if (nbw_env == 4 && nbt > 2) nbw = 4;
         a.halves = (nbt + nbw - 1) / nbw;
-        const int slots = DEC_WAVES / a.halves;
-        int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
-        int rc = nbw == 1 ? launch_decode_nbw<1>(a, lds, grid, stream) : launch_decode_nbw<2>(a, lds, grid, stream);
+        int rc = nbw == 1   ? launch_decode_nbw<1, 16>(a, lds, cus, tiles, stream)
+                 : nbw == 2 ? launch_decode_nbw<2, 16>(a, lds, cus, tiles, stream)
+                            : launch_decode_nbw<4, 12>(a, lds, cus, tiles, stream);
         if (rc != FR_OK) return rc;
     }
     return FR_OK;

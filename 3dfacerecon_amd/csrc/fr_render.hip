@@ -8,20 +8,23 @@
 // triangles are sub-pixel (about half have no pixel centre in their bbox, the rest test ~1 pixel), so the work is
 // "gather 9 floats, maybe emit one hit", then "per-pixel max":
 //
-//   raster_emit_kernel   one lane per (face, triangle), 256-triangle segments, ~26 k small workgroups so that the
-//                        dependent idx -> vertex gathers are hidden by occupancy.  Applies the reference's exact
-//                        integer bbox / whole-triangle-reject rules, computes the fp32 centroid depth and runs the
-//                        fp64 barycentric test on the bbox's pixel centres.  A triangle whose bbox fits an 8x4
-//                        window inside one screen strip emits ONE 16-byte record {key, x0|y0, 32-bit hit mask};
-//                        anything else (large or strip-straddling) emits a "big" record that the resolver
-//                        rasterises itself.  Records are counting-sorted by screen strip inside the segment through
-//                        LDS counters -- no global atomics, no global counters to zero, fixed capacity.
+//   raster_emit_kernel   512-triangle segments (13 k workgroups).  Phase A: each thread takes two triangles, loads
+//                        the float ids (shared by all faces), gathers the nine vertex floats with 32-bit offsets and
+//                        applies the reference's bbox / whole-triangle-reject rules; survivors (~half) are compacted
+//                        into an LDS queue.  Phase B, on dense waves: fp32 centroid depth, packed key, the fp64
+//                        barycentric test on the bbox's pixel centres, the un-normalised normal.  A triangle whose bbox
+//                        fits an 8x4 window inside one screen strip emits ONE 16-byte record {key, x0|y0, 32-bit hit
+//                        mask} (+ its normal in the companion slot); anything else (large or strip-straddling) emits a
+//                        "big" record that the resolver rasterises itself.  Phase C counting-sorts the records by
+//                        screen strip inside the segment through LDS counters -- no global atomics, no global counters
+//                        to zero, fixed capacity.
 //   resolve_write_kernel one workgroup per (face, strip-of-rows) screen bin; the bin's 64-bit keys live in LDS
-//                        (rows*W*8 B).  It pulls only its own bucket of every segment, resolves with ds_max_u64 on
+//                        (rows*W*8 B).  It pulls only its own bucket of every segment as one flat list (bucket sizes
+//                        prefix-summed in LDS, all record loads in flight), resolves with ds_max_u64 on
 //                        key = orderable(h) << 32 | ~tri  (max == "largest h, ties to the lowest index": the serial
-//                        semantics, order independent => deterministic, race free), then unpacks the winners and
-//                        streams the four output planes of its strip with 16-byte stores; texture means and
-//                        normals are recomputed from the winner's vertices, never materialised per triangle.
+//                        semantics, order independent => deterministic, race free); a second pass over the same
+//                        records stores the winners' normals; then depth / tri_ind / texture (per-triangle means from a
+//                        table built once per batch) and the background normals stream out coalesced.
 //   render_strip_kernel  the first-generation path (every bin scans every triangle); kept as the general fallback
 //                        for shapes the binned path does not cover and for A/B runs (FR_RENDER_IMPL=scan).
 //
@@ -50,7 +53,6 @@ struct RenderArgs {
     int nseg;
     float wm1, hm1;        // (float)(W-1), (float)(H-1)
     uint32_t rows_magic;   // ceil(2^32 / rows): y / rows == umulhi(y, magic) for y, rows < 2^16
-    int dbg;               // diagnostic ablation mask (FR_RENDER_DBG), 0 in production
 };
 
 constexpr int SEG = 512;         // triangles (and record capacity) per segment
@@ -169,7 +171,7 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
     float* nrm = a.normal + pix0 * 3;
     const bool vec_ok = ((npix & 3) == 0) && ((pix0 & 3) == 0) &&
                         ((((uintptr_t)a.depth | (uintptr_t)a.tri_ind | (uintptr_t)a.tex_img | (uintptr_t)a.normal) & 15) == 0);
-    if (a.recn != nullptr && ntri > 0 && !(a.dbg & 8)) {
+    if (a.recn != nullptr && ntri > 0) {
         // binned path: the normals of the covered pixels were already stored by the resolver's second pass; here
         // depth / tri_ind / texture go out for every pixel and zeros for the background pixels' normals.  One pixel per
         // lane: neighbouring lanes hold neighbouring pixels -> neighbouring triangles -> shared table lines.
@@ -214,7 +216,7 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
         // (key -> vertex ids -> positions / texture); all loads of the four pixels are issued together and
         // unconditionally (background pixels read triangle 0 with clamped ids and discard it), so a pass costs two
         // memory round trips instead of eight.
-        const bool can_gather = ntri > 0 && nver > 0 && !(a.dbg & 8);
+        const bool can_gather = ntri > 0 && nver > 0;
         const unsigned long long KBG = bg_key();
         for (int g = tid; g < (npix >> 2); g += BLOCK) {
             unsigned long long kk[4];
@@ -669,7 +671,6 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
             __syncthreads();
         }
     }
-    if (a.dbg & 4) return;
     write_strip<BLOCK>(a, b, r0, npix, keys, vx, vy, vz);
 }
 
@@ -768,7 +769,6 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
     a.tex_stride = (tex_batch == 1) ? 0 : 3ll * nver;
     a.recs = nullptr; a.segoff = nullptr; a.nseg = g.nseg;
     a.recn = nullptr; a.tritex_ws = nullptr;
-    a.dbg = env_int("FR_RENDER_DBG", 0);
     a.wm1 = (float)(W - 1);
     a.hm1 = (float)(H - 1);
     a.rows_magic = g.rows > 1 ? (uint32_t)((0x100000000ull + (unsigned)g.rows - 1) / (unsigned)g.rows) : 0u;
@@ -788,8 +788,7 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
     a.segoff = reinterpret_cast<uint16_t*>(wsp + g.recs_bytes);
     a.recn = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes);
     a.tritex_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes + g.nrm_bytes);
-    if (!(a.dbg & 16))
-        hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
     const int rblk = env_int("FR_RESOLVE_BLOCK", 512);
     if (rblk == 256) {
         static unsigned char ok256[64];

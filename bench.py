@@ -170,8 +170,20 @@ def main():
                        "achieved": flops / (decode_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "traffic": None, "avg_ms": decode_ms,
                        "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9}
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json:
+        # FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 correction applied as the microarch guide says)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("batch") == B and (H, W) == (200, 200):
+                roof_render["traffic"] = pmc["render_bytes_per_launch"]
+                roof_decode["traffic"] = pmc["decode_bytes_per_launch"]
+                roof_render["traffic_source"] = roof_decode["traffic_source"] = "profiles/pmc_traffic.json"
+        except (OSError, ValueError, KeyError):
+            pass
         for r in (roof_render, roof_decode):
             r["frac"] = r["achieved"] / r["peak"]
+            r["algorithmic_bytes_per_launch" if r["bound"] == "hbm" else "algorithmic_flop_per_launch"] = \
+                ab["render"] * B if r["bound"] == "hbm" else flops
         dominant = roof_render if render_ms >= decode_ms else roof_decode
         out = {
             "metric": "faces/sec (3DMM decode+depth render), batch 64 @200x200",
