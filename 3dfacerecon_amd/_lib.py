@@ -11,7 +11,7 @@ import threading
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.path.join(_PKG_DIR, "libfr_hotpath.so")
-SOURCES = ["fr_capi.hip", "fr_render.hip", "fr_decode.hip"]
+SOURCES = ["fr_capi.hip", "fr_render.hip", "fr_decode.hip", "fr_decode_bwd.hip"]
 HEADERS = [os.path.join(_CSRC, "fr_common.h"), os.path.join(_PKG_DIR, "..", "include", "fr_hotpath.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -69,11 +69,17 @@ def _bind(L):
     L.fr_decode_pack_basis.restype = _i
     L.fr_decode_3dmm.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp]
     L.fr_decode_3dmm.restype = _i
+    L.fr_decode_backward_workspace_bytes.argtypes = [_i, _i, _i, _i]
+    L.fr_decode_backward_workspace_bytes.restype = ctypes.c_size_t
+    L.fr_decode_3dmm_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp,
+                                          ctypes.c_size_t, _vp]
+    L.fr_decode_3dmm_backward.restype = _i
     return L
 
 
 EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_render_depth_forward",
-           "fr_render_depth_backward", "fr_decode_packed_basis_bytes", "fr_decode_pack_basis", "fr_decode_3dmm"]
+           "fr_render_depth_backward", "fr_decode_packed_basis_bytes", "fr_decode_pack_basis", "fr_decode_3dmm",
+           "fr_decode_backward_workspace_bytes", "fr_decode_3dmm_backward"]
 
 
 def lib():

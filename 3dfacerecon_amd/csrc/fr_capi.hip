@@ -73,4 +73,25 @@ int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R
                             (hipStream_t)hip_stream);
 }
 
+size_t fr_decode_backward_workspace_bytes(int B, int N, int n_shape, int n_exp) {
+    (void)n_shape; (void)n_exp;
+    if (B <= 0 || N <= 0) return 0;
+    return fr_decode_backward_workspace_impl(N);
+}
+
+int fr_decode_3dmm_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
+                            const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N, int n_shape,
+                            int n_exp, float im_size, float* grad_params, void* workspace, size_t ws_bytes,
+                            void* hip_stream) {
+    if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0) return FR_ERR_INVALID_ARG;
+    if (B == 0) return FR_OK;
+    if (!grad_params || !params) return FR_ERR_INVALID_ARG;
+    if (N > 0 && (!grad_vertex_proj || !vertex_proj || (n_shape > 0 && !pc_shape) || (n_exp > 0 && !pc_exp)))
+        return FR_ERR_INVALID_ARG;
+    if (ws_bytes < fr_decode_backward_workspace_bytes(B, N, n_shape, n_exp)) return FR_ERR_WORKSPACE;
+    if (N > 0 && (!workspace || ((uintptr_t)workspace & 15))) return FR_ERR_WORKSPACE;
+    return fr_launch_decode_backward(grad_vertex_proj, params, vertex_proj, pc_shape, pc_exp, R_override, B, N, n_shape,
+                                     n_exp, im_size, grad_params, workspace, (hipStream_t)hip_stream);
+}
+
 }  // extern "C"

@@ -1,0 +1,297 @@
+// 3DMM decode backward for gfx950 (MI355X): dL/d vertex_proj [B,3,N] -> dL/d params [B,235].
+//
+// What it computes: the gradient TF autodiff derives from FaceRecNet.vertices_transform (nets/network.py:140-171):
+//   dq      = (g_x, -g_y, g_z)                                  y row is (im_size - q_1) - 1 (:168)
+//   d t3d_i = sum_p dq_i                                        (:164-165)
+//   d f     = sum_p (R v) . dq  = sum_p (q - t3d) . dq / f      (f_expand * R, :163-165)
+//   dv      = (f R)^T dq ;  d alpha = pc_shape^T dv ;  d beta = pc_exp^T dv          (:153-159)
+//   d angles = 0: R comes out of tf.py_func (:150), which has no gradient in the reference.
+//
+// How: three launches, no float atomics (bit-reproducible):
+//   bwd_prepass_kernel  elementwise: dq -> dv, written transposed into MFMA B-fragment order dvT4[row][16][4]
+//                       (LDS tile transpose so both the read of g and the write of dvT4 are coalesced), plus
+//                       per-workgroup partial sums for d t3d and d f;
+//   bwd_gemm_kernel     the [228 x 3N].[3N x 64] reduction on the matrix cores (exact-f32 v_mfma_f32_16x16x4_f32):
+//                       split over row chunks, one 5-wave workgroup per chunk, wave w owns coefficient blocks
+//                       3w..3w+2 (16 coefficients each; 13 shape blocks + 2 expression blocks), basis^T fragments
+//                       come straight from the reference-layout basis (64-byte row segments), dv fragments are one
+//                       dwordx4 per k-step shared through L1 by the five waves; partial [240 x 64] slabs go to
+//                       the workspace;
+//   bwd_reduce_kernel   sums the slabs / partials in a fixed order and writes grad_params.
+#include "fr_common.h"
+
+namespace fr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BW_PV = 64;        // vertices per prepass workgroup
+constexpr int BW_WAVES = 5;      // gemm waves per workgroup (15 coefficient blocks / 3)
+constexpr int BW_CB = 3;         // coefficient blocks per wave
+constexpr int BW_MAXCOEF = BW_WAVES * BW_CB * 16;  // 240 padded coefficients
+
+struct BwdArgs {
+    const float* g;          // [B,3,N]
+    const float* params;     // [B,nd]
+    const float* vproj;      // [B,3,N] forward output
+    const float* pc_shape;   // [3N,ns]
+    const float* pc_exp;     // [3N,ne]
+    const float* R_override; // [B,9] or null
+    float* grad_params;      // [B,nd]
+    float4* dvT4;            // [3N][16] float4: dv[row][batch = 16*mb + j] at [row][j].mb
+    float* pose_part;        // [prepass blocks][64][4]  (dt_x, dt_y, dt_z, sum (q-t).dq)
+    float* slab;             // [gemm blocks][240][64]
+    int B, N, ns, ne, b0, nbatch;
+    int pre_blocks, gemm_blocks, rows_per_block;
+    float im_size;
+};
+
+__device__ __forceinline__ void bwd_rotation(const BwdArgs& a, int b, float* R9) {
+    const int nd = FR_N_POSE + a.ns + a.ne;
+    const float* pr = a.params + (size_t)(a.b0 + b) * nd;
+    if (a.R_override) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) R9[i] = a.R_override[(size_t)(a.b0 + b) * 9 + i];
+        return;
+    }
+    double sp, cp, sy, cy, st, ct;
+    sincos((double)pr[0], &sp, &cp);
+    sincos((double)pr[1], &sy, &cy);
+    sincos((double)pr[2], &st, &ct);
+    // (R_pitch . R_yaw) . R_roll in float64, 3-term dots without FMA, one rounding (network.py:276-290)
+    const double Rp[9] = {1, 0, 0, 0, cp, sp, 0, -sp, cp};
+    const double Ry[9] = {cy, 0, -sy, 0, 1, 0, sy, 0, cy};
+    const double Rr[9] = {ct, st, 0, -st, ct, 0, 0, 0, 1};
+    double PY[9], Rm[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) PY[3 * i + j] = (Rp[3 * i] * Ry[j] + Rp[3 * i + 1] * Ry[3 + j]) + Rp[3 * i + 2] * Ry[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Rm[3 * i + j] = (PY[3 * i] * Rr[j] + PY[3 * i + 1] * Rr[3 + j]) + PY[3 * i + 2] * Rr[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) R9[i] = (float)Rm[i];
+}
+
+// ---- prepass: 64 vertices x 64 batch columns per workgroup -------------------------------------------------------------
+__global__ __launch_bounds__(256) void bwd_prepass_kernel(BwdArgs a) {
+    __shared__ float Mt[64][13];                 // f*R (9), t (3), 1/f or 0
+    __shared__ float tile[3][BW_PV][64 + 1];      // dv[c][p][bslot]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nd = FR_N_POSE + a.ns + a.ne;
+    const int N = a.N;
+    if (tid < 64) {
+        float m[13];
+#pragma unroll
+        for (int i = 0; i < 13; i++) m[i] = 0.f;
+        if (tid < a.nbatch) {
+            const float* pr = a.params + (size_t)(a.b0 + tid) * nd;
+            float R[9];
+            bwd_rotation(a, tid, R);
+            const float f = pr[6];
+#pragma unroll
+            for (int i = 0; i < 9; i++) m[i] = f * R[i];
+            m[9] = pr[3]; m[10] = pr[4]; m[11] = pr[5];
+            m[12] = (f != 0.0f) ? 1.0f / f : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 13; i++) Mt[tid][i] = m[i];
+    }
+    __syncthreads();
+    const int p = blockIdx.x * BW_PV + lane;
+    const bool pok = p < N;
+    // wave wv handles batch columns 16*wv .. 16*wv+15, lane = vertex: reads of g / vproj are 256-byte coalesced
+    for (int bq = 0; bq < 16; bq++) {
+        const int b = 16 * wv + bq;
+        float dq0 = 0.f, dq1 = 0.f, dq2 = 0.f, fs = 0.f;
+        if (pok && b < a.nbatch) {
+            const float* gb = a.g + (size_t)(a.b0 + b) * 3 * N;
+            const float* vb = a.vproj + (size_t)(a.b0 + b) * 3 * N;
+            dq0 = gb[p];
+            dq1 = -gb[(size_t)N + p];
+            dq2 = gb[2 * (size_t)N + p];
+            // (q - t): q_0 = out_x, q_1 = (im - 1) - out_y, q_2 = out_z
+            const float q0 = vb[p] - Mt[b][9];
+            const float q1 = ((a.im_size - 1.0f) - vb[(size_t)N + p]) - Mt[b][10];
+            const float q2 = vb[2 * (size_t)N + p] - Mt[b][11];
+            fs = __builtin_fmaf(q2, dq2, __builtin_fmaf(q1, dq1, q0 * dq0));
+        }
+        const float* m = Mt[b];
+        const int bslot = (b & 15) * 4 + (b >> 4);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            tile[c][lane][bslot] = __builtin_fmaf(m[6 + c], dq2, __builtin_fmaf(m[3 + c], dq1, m[c] * dq0));
+        // fixed-order wave reduction over the 64 vertices
+        float r0 = dq0, r1 = dq1, r2 = dq2, r3 = fs;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            r0 += __shfl_xor(r0, d);
+            r1 += __shfl_xor(r1, d);
+            r2 += __shfl_xor(r2, d);
+            r3 += __shfl_xor(r3, d);
+        }
+        if (lane == 0) {
+            float* pp = a.pose_part + ((size_t)blockIdx.x * 64 + b) * 4;
+            pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3 * m[12];
+        }
+    }
+    __syncthreads();
+    // flush: rows r = c*N + p, 64 floats (= 16 float4) per row, coalesced
+    for (int i = tid; i < 3 * BW_PV * 16; i += 256) {
+        const int j4 = i & 15, pl = (i >> 4) & (BW_PV - 1), c = i >> 10;
+        const int pp = blockIdx.x * BW_PV + pl;
+        if (pp < N) {
+            const float* t = &tile[c][pl][j4 * 4];
+            a.dvT4[((size_t)c * N + pp) * 16 + j4] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    }
+}
+
+// ---- the reduction over vertices on the matrix cores -------------------------------------------------------------------
+// D^T[coeff][batch] += sum_k basis[row k][coeff] * dv[row k][batch]:  A operand = basis^T (lane l: row r0+(l>>4),
+// coefficient c0+(l&15)), B operand = dv (lane l: row r0+(l>>4), batch 16*mb+(l&15)).
+__global__ __launch_bounds__(BW_WAVES * 64) void bwd_gemm_kernel(BwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long rows = 3ll * a.N;
+    const long long r_begin = (long long)blockIdx.x * a.rows_per_block;
+    const long long r_end = min(rows, r_begin + a.rows_per_block);
+    const int GSB = (a.ns + 15) / 16;  // shape coefficient blocks
+    const int kq = lane >> 4, jn = lane & 15;
+    // this wave's three coefficient blocks: source array, row stride, column of this lane, validity
+    const float* src[BW_CB];
+    int stride[BW_CB], col[BW_CB];
+    bool cok[BW_CB];
+#pragma unroll
+    for (int t = 0; t < BW_CB; t++) {
+        const int cb = wave * BW_CB + t;
+        if (cb < GSB) {
+            src[t] = a.pc_shape; stride[t] = a.ns; col[t] = cb * 16 + jn; cok[t] = col[t] < a.ns;
+        } else {
+            src[t] = a.pc_exp; stride[t] = a.ne; col[t] = (cb - GSB) * 16 + jn; cok[t] = col[t] < a.ne;
+        }
+    }
+    f32x4 acc[BW_CB][4];
+#pragma unroll
+    for (int t = 0; t < BW_CB; t++)
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (long long r = r_begin; r < r_end; r += 4) {
+        const long long rr = r + kq;
+        const bool rok = rr < r_end;
+        const float4 dv = rok ? a.dvT4[(size_t)rr * 16 + jn] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float av[BW_CB];
+#pragma unroll
+        for (int t = 0; t < BW_CB; t++) av[t] = (rok && cok[t]) ? src[t][(size_t)rr * stride[t] + col[t]] : 0.f;
+#pragma unroll
+        for (int t = 0; t < BW_CB; t++) {
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], dv.x, acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], dv.y, acc[t][1], 0, 0, 0);
+            acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], dv.z, acc[t][2], 0, 0, 0);
+            acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], dv.w, acc[t][3], 0, 0, 0);
+        }
+    }
+    // D^T tile: row (coefficient within block) = 4*(lane>>4) + reg, column (batch within block) = lane & 15
+    float* slab = a.slab + (size_t)blockIdx.x * BW_MAXCOEF * 64;
+#pragma unroll
+    for (int t = 0; t < BW_CB; t++)
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                const int coef = (wave * BW_CB + t) * 16 + 4 * kq + rg;
+                slab[(size_t)coef * 64 + 16 * mb + jn] = acc[t][mb][rg];
+            }
+}
+
+// ---- fixed-order reduction of the partials ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bwd_reduce_kernel(BwdArgs a) {
+    const int nd = FR_N_POSE + a.ns + a.ne;
+    const int GSB = (a.ns + 15) / 16;
+    const int total = 64 * (4 + BW_MAXCOEF);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i & 63, what = i >> 6;
+        if (b >= a.nbatch) continue;
+        float* gp = a.grad_params + (size_t)(a.b0 + b) * nd;
+        if (what < 4) {
+            float s = 0.f;
+            for (int k = 0; k < a.pre_blocks; k++) s += a.pose_part[((size_t)k * 64 + b) * 4 + what];
+            if (what < 3) {
+                gp[3 + what] = s;
+                gp[what] = 0.0f;  // angles: no gradient through tf.py_func (network.py:150)
+            } else {
+                gp[6] = s;
+            }
+        } else {
+            const int coef = what - 4;
+            const int cb = coef >> 4, cc = coef & 15;
+            int dst = -1;
+            if (cb < GSB) {
+                if (cb * 16 + cc < a.ns) dst = FR_N_POSE + cb * 16 + cc;
+            } else if ((cb - GSB) * 16 + cc < a.ne) {
+                dst = FR_N_POSE + a.ns + (cb - GSB) * 16 + cc;
+            }
+            if (dst < 0) continue;
+            float s = 0.f;
+            for (int k = 0; k < a.gemm_blocks; k++) s += a.slab[((size_t)k * BW_MAXCOEF + coef) * 64 + b];
+            gp[dst] = s;
+        }
+    }
+}
+
+struct BwdGeom {
+    int pre_blocks, gemm_blocks, rows_per_block;
+    size_t dv_bytes, pose_bytes, slab_bytes;
+};
+static BwdGeom bwd_geom(int N) {
+    BwdGeom g;
+    g.pre_blocks = (N + BW_PV - 1) / BW_PV;
+    const long long rows = 3ll * N;
+    long long want = 512;
+    long long rpb = (rows + want - 1) / want;
+    rpb = ((rpb + 3) / 4) * 4;
+    if (rpb < 4) rpb = 4;
+    g.rows_per_block = (int)rpb;
+    g.gemm_blocks = (int)((rows + rpb - 1) / rpb);
+    g.dv_bytes = (size_t)rows * 16 * sizeof(float4);
+    g.pose_bytes = (((size_t)g.pre_blocks * 64 * 4 * sizeof(float)) + 15) & ~(size_t)15;
+    g.slab_bytes = (size_t)g.gemm_blocks * BW_MAXCOEF * 64 * sizeof(float);
+    return g;
+}
+
+}  // namespace fr
+
+size_t fr_decode_backward_workspace_impl(int N) {
+    if (N <= 0) return 0;
+    fr::BwdGeom g = fr::bwd_geom(N);
+    return g.dv_bytes + g.pose_bytes + g.slab_bytes;
+}
+
+int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
+                              const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N, int ns,
+                              int ne, float im_size, float* grad_params, void* workspace, hipStream_t stream) {
+    using namespace fr;
+    if (B == 0) return FR_OK;
+    const int nd = FR_N_POSE + ns + ne;
+    if (N == 0) return hipMemsetAsync(grad_params, 0, (size_t)B * nd * sizeof(float), stream) == hipSuccess ? FR_OK
+                                                                                                             : FR_ERR_LAUNCH;
+    if ((ns + 15) / 16 + (ne + 15) / 16 > BW_WAVES * BW_CB) return FR_ERR_UNSUPPORTED;  // > 240 padded coefficients
+    BwdGeom g = bwd_geom(N);
+    BwdArgs a;
+    a.g = grad_vertex_proj; a.params = params; a.vproj = vertex_proj;
+    a.pc_shape = pc_shape; a.pc_exp = pc_exp; a.R_override = R_override; a.grad_params = grad_params;
+    char* ws = reinterpret_cast<char*>(workspace);
+    a.dvT4 = reinterpret_cast<float4*>(ws);
+    a.pose_part = reinterpret_cast<float*>(ws + g.dv_bytes);
+    a.slab = reinterpret_cast<float*>(ws + g.dv_bytes + g.pose_bytes);
+    a.B = B; a.N = N; a.ns = ns; a.ne = ne; a.im_size = im_size;
+    a.pre_blocks = g.pre_blocks; a.gemm_blocks = g.gemm_blocks; a.rows_per_block = g.rows_per_block;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        a.b0 = b0;
+        a.nbatch = min(B - b0, 64);
+        hipLaunchKernelGGL(bwd_prepass_kernel, dim3(g.pre_blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(bwd_gemm_kernel, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
+        hipLaunchKernelGGL(bwd_reduce_kernel, dim3(64), dim3(256), 0, stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
+}

@@ -39,6 +39,44 @@ def _ops():
     return _load("_fr_hotpath_ops", os.path.join("rendering_layer", "ops.py"))
 
 
+class _Decode3DMM(torch.autograd.Function):
+    """vertices_transform as one autograd node: fr_decode_3dmm forward, fr_decode_3dmm_backward for the gradient TF
+    autodiff derives from network.py:140-171 (d alpha, d beta, d t3d, d f; the three angles get zero because the
+    reference's rotation goes through tf.py_func, network.py:150, which has no gradient)."""
+
+    @staticmethod
+    def forward(ctx, params, net, R):
+        h = _host()
+        B = int(params.shape[0])
+        out = torch.empty((B, 3, net.nvert), dtype=torch.float32, device=params.device)
+        with torch.cuda.device(params.device):
+            rc = h.lib().fr_decode_3dmm(h.ptr(params), h.ptr(net._packed), h.ptr(R), B, net.nvert, net.ndim_shape,
+                                        net.ndim_exp, float(net.im_size), h.ptr(out), h.stream_ptr(params.device))
+        h.check(rc, "fr_decode_3dmm")
+        ctx.net = net
+        ctx.save_for_backward(params, out, R if R is not None else params.new_empty(0))
+        ctx.has_R = R is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        h = _host()
+        net = ctx.net
+        params, out, R = ctx.saved_tensors
+        B = int(params.shape[0])
+        g = h.require_gpu_f32(grad_out, "grad_vertex_proj")
+        gp = torch.empty_like(params)
+        L = h.lib()
+        with torch.cuda.device(params.device):
+            nws = L.fr_decode_backward_workspace_bytes(B, net.nvert, net.ndim_shape, net.ndim_exp)
+            ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=params.device)
+            rc = L.fr_decode_3dmm_backward(h.ptr(g), h.ptr(params), h.ptr(out), h.ptr(net.pc_shape), h.ptr(net.pc_exp),
+                                           h.ptr(R) if ctx.has_R else None, B, net.nvert, net.ndim_shape, net.ndim_exp,
+                                           float(net.im_size), h.ptr(gp), h.ptr(ws), nws, h.stream_ptr(params.device))
+        h.check(rc, "fr_decode_3dmm_backward")
+        return gp, None, None
+
+
 class FaceRecNet:
     def __init__(self, im_gray=None, params_label=None, mesh_data=None, nIter=4, batch_size=64, im_size=200,
                  weight_decay=1e-4, device="cuda"):
@@ -108,12 +146,7 @@ class FaceRecNet:
             Rc = h.require_gpu_f32(torch.as_tensor(R, dtype=torch.float32, device=p.device), "R")
             if tuple(Rc.shape) != (B, 3, 3):
                 raise ValueError("R must be (B,3,3)")
-        out = torch.empty((B, 3, self.nvert), dtype=torch.float32, device=p.device)
-        with torch.cuda.device(p.device):
-            rc = h.lib().fr_decode_3dmm(h.ptr(p), h.ptr(self._packed), h.ptr(Rc), B, self.nvert, self.ndim_shape,
-                                        self.ndim_exp, float(self.im_size), h.ptr(out), h.stream_ptr(p.device))
-        h.check(rc, "fr_decode_3dmm")
-        return out
+        return _Decode3DMM.apply(p, self, Rc)
 
     # ---- rendering layer wrapper --------------------------------------------------------------------------
     def rendering_layer(self, vertex_proj, triangles, colors, im_gray=None):

@@ -85,6 +85,19 @@ int fr_decode_pack_basis(const float* mu, const float* pc_shape, const float* pc
 int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R_override, int B, int N,
                    int n_shape, int n_exp, float im_size, float* vertex_proj, void* hip_stream);
 
+/* ---- 3DMM decode backward (the gradient TF autodiff derives from nets/network.py:140-171) ------------
+ *   grad_vertex_proj [B,3,N] = dL/d vertex_proj;  vertex_proj [B,3,N] = the forward output (used for d f);
+ *   mu / pc_shape / pc_exp in the reference layouts (not the packed image);  grad_params [B, 7+n_shape+n_exp].
+ * d alpha = pc_shape^T dv, d beta = pc_exp^T dv with dv = (f R)^T dq, dq = (g_x, -g_y, g_z); d t3d = sum_p dq;
+ * d f = sum_p (q - t3d) . dq / f (0 when f == 0); the three angles get 0: in the reference R passes through tf.py_func
+ * (network.py:150), which has no gradient.  Deterministic (fixed-order partial sums, no float atomics). */
+size_t fr_decode_backward_workspace_bytes(int B, int N, int n_shape, int n_exp);
+
+int fr_decode_3dmm_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
+                            const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N,
+                            int n_shape, int n_exp, float im_size, float* grad_params, void* workspace, size_t ws_bytes,
+                            void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -421,3 +421,56 @@ int fr_oracle_decode_3dmm_f64(const float* params, const float* mu, const float*
     }
     return 0;
 }
+
+/* ---- decode backward: gradient of the 235-d parameters -------------------------------------
+ * What TF autodiff produces for nets/network.py:140-171 given g = dL/d vertex_proj [B,3,N]:
+ *   dq = (g_x, -g_y, g_z)                         (the y row is (im_size - q_1) - 1, network.py:168)
+ *   dt3d_i = sum_p dq_i                           (t3d_expand, :164-165)
+ *   df     = sum_p sum_i (R v)_i dq_i             (f_expand * R, :163-165)
+ *   dv_c   = sum_i (f R)_ic dq_i;  dalpha_k = sum_r pc_shape[r,k] dv_r;  dbeta_k = sum_r pc_exp[r,k] dv_r   (:153-159)
+ *   the three angles get NO gradient: R comes out of tf.py_func (:150), which has no registered gradient.
+ * Evaluated in float64 (the tolerance reference for the fp32 HIP kernels).  grad_params [B, 7+ns+ne]. */
+int fr_oracle_decode_3dmm_backward_f64(const float* grad_vertex_proj, const float* params, const float* mu,
+                                       const float* pc_shape, const float* pc_exp, int B, int N, int ns, int ne,
+                                       double* grad_params) {
+    if (B < 0 || N < 0 || ns < 0 || ne < 0) return -1;
+    int nd = 7 + ns + ne;
+    double* dv = (double*)malloc(sizeof(double) * 3 * (size_t)(N > 0 ? N : 1));
+    if (!dv) return -2;
+    for (int b = 0; b < B; b++) {
+        const float* pr = params + (size_t)b * nd;
+        double* gp = grad_params + (size_t)b * nd;
+        for (int i = 0; i < nd; i++) gp[i] = 0.0;
+        float Rf[9];
+        fr_oracle_rotation_matrix(pr[0], pr[1], pr[2], Rf);
+        double f = pr[6];
+        const float* gx = grad_vertex_proj + ((size_t)b * 3 + 0) * N;
+        const float* gy = grad_vertex_proj + ((size_t)b * 3 + 1) * N;
+        const float* gz = grad_vertex_proj + ((size_t)b * 3 + 2) * N;
+        for (int p = 0; p < N; p++) {
+            double dq[3] = {(double)gx[p], -(double)gy[p], (double)gz[p]};
+            double v[3];
+            for (int c = 0; c < 3; c++) {
+                size_t r = (size_t)c * N + p;
+                double S = 0, E = 0;
+                for (int k = 0; k < ns; k++) S += (double)pc_shape[r * ns + k] * (double)pr[7 + k];
+                for (int k = 0; k < ne; k++) E += (double)pc_exp[r * ne + k] * (double)pr[7 + ns + k];
+                v[c] = (double)mu[r] + S + E;
+            }
+            for (int i = 0; i < 3; i++) {
+                gp[3 + i] += dq[i];
+                gp[6] += ((double)Rf[3 * i] * v[0] + (double)Rf[3 * i + 1] * v[1] + (double)Rf[3 * i + 2] * v[2]) * dq[i];
+            }
+            for (int c = 0; c < 3; c++)
+                dv[(size_t)c * N + p] = f * ((double)Rf[c] * dq[0] + (double)Rf[3 + c] * dq[1] + (double)Rf[6 + c] * dq[2]);
+        }
+        for (size_t r = 0; r < (size_t)3 * N; r++) {
+            double d = dv[r];
+            if (d == 0.0) continue;
+            for (int k = 0; k < ns; k++) gp[7 + k] += (double)pc_shape[r * ns + k] * d;
+            for (int k = 0; k < ne; k++) gp[7 + ns + k] += (double)pc_exp[r * ne + k] * d;
+        }
+    }
+    free(dv);
+    return 0;
+}

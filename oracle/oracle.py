@@ -60,6 +60,8 @@ def lib():
             fn.restype = ctypes.c_int
         L.fr_oracle_decode_3dmm_f64.argtypes = [_f32p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_double, _f64p]
         L.fr_oracle_decode_3dmm_f64.restype = ctypes.c_int
+        L.fr_oracle_decode_3dmm_backward_f64.argtypes = [_f32p] * 5 + [ctypes.c_int] * 4 + [_f64p]
+        L.fr_oracle_decode_3dmm_backward_f64.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -188,6 +190,23 @@ def decode_3dmm_f64(params, mu, pc_shape, pc_exp, im_size):
                                          float(im_size), out.ctypes.data_as(_f64p))
     if rc != 0:
         raise ValueError("fr_oracle_decode_3dmm_f64 rc=%d" % rc)
+    return out
+
+
+def decode_3dmm_backward_f64(grad_vertex_proj, params, mu, pc_shape, pc_exp):
+    """float64 gradient of the parameters given dL/d vertex_proj [B,3,N] (what TF autodiff yields for
+    nets/network.py:140-171: no gradient to the three angles, which pass through tf.py_func)."""
+    g, gp = _c32(grad_vertex_proj)
+    params, pp = _c32(params)
+    mu, mp = _c32(np.asarray(mu).reshape(-1))
+    pc_shape, sp = _c32(pc_shape)
+    pc_exp, ep = _c32(pc_exp)
+    B, N = params.shape[0], mu.shape[0] // 3
+    out = np.empty((B, params.shape[1]), np.float64)
+    rc = lib().fr_oracle_decode_3dmm_backward_f64(gp, pp, mp, sp, ep, B, N, pc_shape.shape[1], pc_exp.shape[1],
+                                                  out.ctypes.data_as(_f64p))
+    if rc != 0:
+        raise ValueError("fr_oracle_decode_3dmm_backward_f64 rc=%d" % rc)
     return out
 
 

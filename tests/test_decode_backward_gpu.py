@@ -1,0 +1,78 @@
+"""GPU parity: fr_decode_3dmm_backward (HIP, MFMA reduction over the vertices) vs a float64 evaluation of the gradient
+TF autodiff derives from nets/network.py:140-171.  The kernels sum in fixed-order fp32 partials, so the comparison is a
+tolerance relative to the magnitude of the summed terms; the result itself is bit-reproducible run to run."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import net_mod, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(rs, B, ns, ne):
+    P = np.zeros((B, 7 + ns + ne), np.float32)
+    P[:, 0:3] = rs.uniform(-1.0, 1.0, (B, 3))
+    P[:, 3:5] = rs.uniform(60, 140, (B, 2))
+    P[:, 5] = rs.uniform(-1, 1, B)
+    P[:, 6] = rs.uniform(2e-4, 1e-3, B)
+    P[:, 7:7 + ns] = rs.uniform(0, 1e4, (B, ns))
+    P[:, 7 + ns:] = rs.uniform(-1.5, 1.5, (B, ne))
+    return P
+
+
+def _check(oracle, A, P, G, tol=2e-5):
+    net = net_mod().FaceRecNet(mesh_data=A, batch_size=P.shape[0], im_size=200)
+    p = torch.as_tensor(P, device="cuda:0").requires_grad_(True)
+    V = net.vertices_transform(p)
+    V.backward(torch.as_tensor(G, device="cuda:0"))
+    got = p.grad.cpu().numpy().astype(np.float64)
+    want = oracle.decode_3dmm_backward_f64(G, P, A["mu"], A["pc_shape"], A["pc_exp"])
+    ns = A["ndim_shape"]
+    assert np.all(got[:, 0:3] == 0) and np.all(want[:, 0:3] == 0)       # angles: no gradient (tf.py_func)
+    # scale of the sums behind each block of outputs
+    for sl in (slice(3, 6), slice(6, 7), slice(7, 7 + ns), slice(7 + ns, None)):
+        scale = np.abs(want[:, sl]).max() + 1e-30
+        err = np.abs(got[:, sl] - want[:, sl]).max() / scale
+        assert err < tol, (sl, err)
+    return got
+
+
+@pytest.mark.parametrize("gu,gv,ns,ne,B", [(7, 9, 3, 2, 2), (20, 24, 9, 5, 5), (13, 17, 199, 29, 17), (9, 10, 40, 7, 65)])
+def test_vs_f64_small(oracle, synth, gu, gv, ns, ne, B):
+    A = synth.make_assets(gu, gv, ns, ne, patch=None, seed_basis=gu + gv)
+    rs = np.random.RandomState(B)
+    P = _params(rs, B, ns, ne)
+    G = rs.standard_normal((B, 3, gu * gv)).astype(np.float32)
+    _check(oracle, A, P, G)
+
+
+def test_full_size_deterministic(oracle, full_assets):
+    A = full_assets
+    rs = np.random.RandomState(3)
+    B = 3
+    P = _params(rs, B, 199, 29)
+    G = (rs.standard_normal((B, 3, 53215)) * rs.uniform(0, 1, (B, 3, 53215))).astype(np.float32)
+    got1 = _check(oracle, A, P, G, tol=5e-5)
+    got2 = _check(oracle, A, P, G, tol=5e-5)
+    np.testing.assert_array_equal(got1, got2)      # no float atomics: bit-reproducible
+
+
+def test_gradient_flows_from_depth_to_params(full_assets, synth):
+    """CoarseNet -> render loop: d(depth loss)/d params through render backward (z only) and decode backward."""
+    A = full_assets
+    net = net_mod().FaceRecNet(mesh_data=A, batch_size=2, im_size=200)
+    P = torch.as_tensor(synth.sample_params_batch(2, beta=0.7, seed=4), device="cuda:0").requires_grad_(True)
+    V = net.vertices_transform(P)
+    depth = ops().render_depth(V, net.tri, net.vertex_code, torch.zeros((2, 200, 200, 3), device="cuda:0"))[0]
+    loss = depth.clamp_min(1e-6).sum()
+    loss.backward()
+    g = P.grad
+    assert bool(torch.isfinite(g).all())
+    assert float(g[:, 0:3].abs().max()) == 0.0          # angles
+    assert float(g[:, 3:5].abs().max()) == 0.0          # tx, ty: depth only feeds the z row
+    assert float(g[:, 5].abs().min()) > 0.0             # tz: every covered pixel contributes g/3 * 3
+    assert float(g[:, 7:].abs().max()) > 0.0
+    # d loss / d tz == number of covered pixels with depth > 1e-6 (each hands out 3 * 1/3)
+    ncov = (depth > 1e-6).sum(dim=(1, 2, 3)).float()
+    assert torch.allclose(g[:, 5], ncov, rtol=1e-4)

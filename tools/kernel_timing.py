@@ -44,6 +44,17 @@ def main():
     print("decode+render %.1f us" % timeit(plan.step, args.iters))
     plan.capture()
     print("graph replay  %.1f us" % timeit(plan.replay, args.iters))
+    # backward legs (autograd surface): depth -> vertex z -> params
+    ops = pkg("rendering_layer.ops")
+    P = plan.params.clone().requires_grad_(True)
+    V = net.vertices_transform(P)
+    outs = ops.render_depth(V, net.tri, net.vertex_code, torch.zeros((args.batch, 200, 200, 3), device="cuda:0"))
+    g = torch.ones_like(outs[0])
+
+    def bwd():
+        P.grad = None
+        outs[0].backward(g, retain_graph=True)
+    print("render+decode backward %.1f us" % timeit(bwd, args.iters))
 
 
 if __name__ == "__main__":
