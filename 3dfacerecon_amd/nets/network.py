@@ -175,6 +175,22 @@ class FaceRecNet:
         depthimg_batch = torch.clamp_min(depth, 1e-6)
         return pncc_batch, normalimg_batch, maskimg_batch, depthimg_batch
 
+    def compute_abedo_image(self, vertices, triangles, abedos, im_gray=None):
+        """Albedo (3,N) -> albedo image + normalised normal map through a second render (network.py:394-417)."""
+        ver = vertices.float()
+        tri = torch.as_tensor(triangles, dtype=torch.float32, device=ver.device)
+        tex = torch.as_tensor(abedos, dtype=torch.float32, device=ver.device)
+        B = ver.shape[0]
+        image = torch.zeros((B, self.im_size, self.im_size, 3), dtype=torch.float32, device=ver.device)
+        _, tf_abedo, normal, _ = _ops().render_depth(ver=ver, tri=tri, texture=tex, image=image)
+        abedos_image = torch.clamp_min(tf_abedo, 1e-6).mean(dim=-1, keepdim=True)  # (B, H, W, 1)
+        flip = normal[..., 2:3] < 0
+        normal = torch.where(flip, -1.0 * normal, normal)
+        mag = (normal * normal).sum(-1)
+        mag = torch.where(mag > 1e-6, mag, torch.ones_like(mag))
+        normal_map = normal / (torch.sqrt(mag) + 1e-6)[..., None]
+        return abedos_image, normal_map
+
     def depth_rendering_layer(self):
         """(network.py:300-309)"""
         self.vertices_proj = self.vertices_transform(self.pred_params)

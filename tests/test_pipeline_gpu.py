@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from gpu_util import assert_render_equal, net_mod, ops
+from conftest import pkg as pkg_mod
 
 pytestmark = pytest.mark.gpu
 
@@ -86,3 +87,24 @@ def test_plan_matches_operator_surface(full_assets, synth):
     got2 = [o.clone() for o in plan.replay(P)]
     for g, w in zip(got2, want):
         assert torch.equal(g, w)
+
+
+def test_compute_abedo_image_and_mat_assets(tmp_path, small_assets):
+    """network.py:394-417 on assets that went through the .mat contract of utils/parser_3dmm.py."""
+    parser = pkg_mod("utils.parser_3dmm")
+    parser.write_3dmm_model(str(tmp_path), small_assets, tri_base=1)
+    M = parser.read_3dmm_model(str(tmp_path), tri_base=1)
+    net = net_mod().FaceRecNet(mesh_data=M, batch_size=2, im_size=40)
+    P = np.zeros((2, net.ndim), np.float32)
+    P[:, 3:5] = 20.0
+    P[:, 6] = 2e-4
+    V = net.vertices_transform(torch.as_tensor(P, device="cuda:0"))
+    alb, nmap = net.compute_abedo_image(V, net.tri, M['mu_tex'])
+    assert tuple(alb.shape) == (2, 40, 40, 1) and tuple(nmap.shape) == (2, 40, 40, 3)
+    assert float(alb.min()) >= float(np.float32(1e-6)) and float(alb.max()) <= 1.0
+    assert float(nmap[..., 2].min()) >= 0.0
+    # same render through the op surface
+    _, tex, _, tind = ops().render_depth(V, net.tri, torch.as_tensor(np.asarray(M['mu_tex'], np.float32), device="cuda:0"),
+                                         torch.zeros((2, 40, 40, 3), device="cuda:0"))
+    assert torch.equal(alb, tex.clamp_min(1e-6).mean(-1, keepdim=True))
+    assert float((tind >= 0).float().mean()) > 0.1
