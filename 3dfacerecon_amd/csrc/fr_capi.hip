@@ -38,6 +38,21 @@ int fr_render_depth_forward(const float* vertex, const float* tri, const float* 
                                     tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream);
 }
 
+int fr_rendering_layer_forward(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
+                               int nver, int ntri, int H, int W, int tex_batch, float* net_input, float* depth_img,
+                               float* depth, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream) {
+    if (B < 0 || nver < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
+    if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
+    if ((size_t)B * H * W == 0) return FR_OK;
+    if (!net_input || !depth_img || !depth || !tri_ind || !im_gray) return FR_ERR_INVALID_ARG;
+    if (ntri > 0 && (!tri || (nver > 0 && (!vertex || !texture)))) return FR_ERR_INVALID_ARG;
+    if (ntri >= (1 << 24)) return FR_ERR_UNSUPPORTED;
+    if (ntri == 0 || nver == 0) return FR_ERR_UNSUPPORTED;  // nothing to fuse: use the plain op
+    if (ws_bytes < fr_render_depth_workspace_bytes(B, nver, ntri, H, W)) return FR_ERR_WORKSPACE;
+    return fr_launch_rendering_layer(vertex, tri, texture, im_gray, B, nver, ntri, H, W, tex_batch, net_input, depth_img,
+                                     depth, tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream);
+}
+
 int fr_render_depth_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
                              int B, int nver, int ntri, int H, int W, void* hip_stream) {
     if (B < 0 || nver < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;

@@ -51,6 +51,10 @@ struct RenderArgs {
     float4* recn;          // [B][nseg][SEG] un-normalised normal (xyz) of the record in the same slot of `recs`
     float4* tritex_ws;     // [tex_batch][ntri] per-triangle texture mean (one copy when the texture is shared)
     int nseg;
+    // fused rendering-layer outputs (fr_rendering_layer_forward; network.py:185-199 folded into the resolver)
+    const float* im_gray;  // [B,H,W,1]
+    float* net_in;         // [B,H,W,7] = [mask*im | pncc x3 | normalised normal x3]  (network.py:122)
+    float* depth_img;      // [B,H,W,1] = max(depth, 1e-6)
     float wm1, hm1;        // (float)(W-1), (float)(H-1)
     uint32_t rows_magic;   // ceil(2^32 / rows): y / rows == umulhi(y, magic) for y, rows < 2^16
 };
@@ -71,13 +75,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // One triangle against one strip [r0, r1): the reference's per-triangle body (render_depth_op.cc:201-219, 263-316)
 // with the depth test replaced by the packed-key LDS max.
 // WINNER = false: resolve (LDS max).  WINNER = true: second pass -- the pixels whose resolved key is this triangle's
-// get `nval` stored to the normal plane `nplane` (strip-relative pixel index * 3).
+// get `nval` stored at `nplane + nstride * pixel` (the strip's normal plane, or the normal channels of the fused
+// 7-channel output).
 template <bool WINNER = false>
 __device__ __forceinline__ void raster_triangle_into_strip(int t, const float* __restrict__ tri,
                                                            const float* __restrict__ vx, const float* __restrict__ vy,
                                                            const float* __restrict__ vz, int nver, int ntri, int H,
                                                            int W, int r0, int r1, unsigned long long* keys,
-                                                           float* nplane = nullptr, float4 nval = float4()) {
+                                                           float* nplane = nullptr, float4 nval = float4(),
+                                                           int nstride = 3) {
     // vertex ids: (int) truncation of float-stored indices, render_depth_op.cc:204-206
     int p1 = f2i_x86(tri[t]);
     int p2 = f2i_x86(tri[(size_t)ntri + t]);
@@ -106,7 +112,7 @@ __device__ __forceinline__ void raster_triangle_into_strip(int t, const float* _
                 if constexpr (!WINNER) {
                     atomicMax(&row[x], key);
                 } else if (row[x] == key) {
-                    float* np = nplane + 3 * ((size_t)(y - r0) * W + x);
+                    float* np = nplane + (size_t)nstride * ((size_t)(y - r0) * W + x);
                     np[0] = nval.x;
                     np[1] = nval.y;
                     np[2] = nval.z;
@@ -115,6 +121,18 @@ __device__ __forceinline__ void raster_triangle_into_strip(int t, const float* _
         }
     }
 }
+
+// Caller-side post-processing of the reference's rendering_layer (nets/network.py:185-199), fused variant.
+// normal: flip to n_z >= 0, divide by sqrt(|n|^2) + 1e-6 with |n|^2 <= 1e-6 replaced by 1 (:188-192)
+__device__ __forceinline__ float4 post_normal(float4 n) {
+    float nx = n.x, ny = n.y, nz = n.z;
+    if (nz < 0.0f) { nx = -1.0f * nx; ny = -1.0f * ny; nz = -1.0f * nz; }
+    float mag = (nx * nx + ny * ny) + nz * nz;
+    mag = (mag > 1e-6f) ? mag : 1.0f;
+    const float d = sqrtf(mag) + 1e-6f;
+    return make_float4(nx / d, ny / d, nz / d, 0.0f);
+}
+__device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 1e-6f), 1.0f); }  // tf.clip_by_value(v,1e-6,1)
 
 struct PixelOut {
     float depth, tind;
@@ -153,6 +171,64 @@ __device__ __forceinline__ PixelOut resolve_pixel(unsigned long long key, const 
     o.nrm[1] = (float)(az * bx - ax * bz);
     o.nrm[2] = (float)(ax * by - ay * bx);
     return o;
+}
+
+// Fused rendering-layer output of one strip (binned path only): [mask*im | pncc | normal] + depth image + raw depth +
+// tri_ind.  The covered pixels' normalised normals were stored by the resolver's second pass; here the background
+// pixels get zeros (the post-processing maps a zero normal to zero, network.py:190-192).
+template <int BLOCK>
+__device__ __forceinline__ void write_strip_fused(const RenderArgs& a, int b, int r0, int npix,
+                                                  const unsigned long long* keys) {
+    const int tid = threadIdx.x;
+    const int ntri = a.ntri;
+    const size_t pix0 = ((size_t)b * a.H + r0) * a.W;
+    float* dep = a.depth + pix0;
+    float* tin = a.tri_ind + pix0;
+    float* dim = a.depth_img + pix0;
+    float* nin = a.net_in + pix0 * 7;
+    const float* __restrict__ img = a.im_gray + pix0;
+    const float4* __restrict__ tws = a.tritex_ws + (a.tex_stride ? (size_t)b * ntri : 0);
+    const unsigned long long KBG = bg_key();
+    constexpr int UNR = 4;
+    for (int i0 = tid; i0 < npix; i0 += BLOCK * UNR) {
+        unsigned long long kk[UNR];
+        bool cov[UNR];
+        int t[UNR];
+        float4 tv[UNR];
+        float im[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int i = i0 + u * BLOCK;
+            kk[u] = (i < npix) ? keys[i] : KBG;
+            cov[u] = kk[u] != KBG;
+            t[u] = cov[u] ? (int)(0xFFFFFFFFu - (uint32_t)kk[u]) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            tv[u] = tws[t[u]];
+            im[u] = img[min(i0 + u * BLOCK, npix - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int i = i0 + u * BLOCK;
+            if (i < npix) {
+                const float d = cov[u] ? f32_unord((uint32_t)(kk[u] >> 32)) : bg_depth();
+                dep[i] = d;
+                tin[i] = cov[u] ? (float)t[u] : -1.0f;
+                dim[i] = fmaxf(d, 1e-6f);                                   // depthimg, network.py:199
+                float* o = nin + 7 * (size_t)i;
+                o[0] = clip01(d) * im[u];                                   // mask * im_gray, :195-196
+                o[1] = clip01(cov[u] ? tv[u].x : 0.0f);                     // pncc, :185
+                o[2] = clip01(cov[u] ? tv[u].y : 0.0f);
+                o[3] = clip01(cov[u] ? tv[u].z : 0.0f);
+                if (!cov[u]) {
+                    o[4] = 0.0f;
+                    o[5] = 0.0f;
+                    o[6] = 0.0f;
+                }
+            }
+        }
+    }
 }
 
 // resolve + write the strip's four planes from the LDS keys (16-byte stores when the strip is 4-pixel aligned)
@@ -553,7 +629,7 @@ constexpr size_t resolve_scratch_bytes(int block) { return (size_t)(block + 1) *
 // The bin's records are spread over the face's segments (a few per segment).  Walking segments one after the other
 // would serialise ~4 dependent memory round trips per segment; instead the per-segment counts are prefix-summed in
 // LDS and the threads take records from the flattened list, so all record loads of a bin are in flight together.
-template <int BLOCK>
+template <int BLOCK, bool FUSED = false>
 __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
     const int tid = threadIdx.x;
@@ -573,7 +649,11 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.nver;
     const float* __restrict__ vy = vx + a.nver;
     const float* __restrict__ vz = vy + a.nver;
-    float* nplane = a.normal + (((size_t)b * a.H + r0) * W) * 3;  // the strip's slice of the normal plane
+    // where the winners' normals go: the strip's slice of the normal plane, or (fused) channels 4..6 of the 7-channel
+    // CoarseNet input, post-processed
+    constexpr int NSTRIDE = FUSED ? 7 : 3;
+    float* nplane = FUSED ? a.net_in + (((size_t)b * a.H + r0) * W) * 7 + 4
+                          : a.normal + (((size_t)b * a.H + r0) * W) * 3;
     constexpr int RU = 4;  // records per lane per trip: all loads in flight before the first LDS operation
 
     // pass 0: z-resolve -- every hit becomes one ds_max_u64.  pass 1: the winners are known; each record looks its hit
@@ -635,11 +715,12 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                             if (keys[p0 + (bit >> 3) * W + (bit & 7)] == key) won |= 1u << bit;
                         }
                         if (won) {
-                            const float4 nv = Nbase[slot[u]];
+                            float4 nv = Nbase[slot[u]];
+                            if (FUSED) nv = post_normal(nv);
                             while (won) {
                                 const int bit = __ffs((int)won) - 1;
                                 won &= won - 1;
-                                float* np = nplane + 3 * (p0 + (bit >> 3) * W + (bit & 7));
+                                float* np = nplane + NSTRIDE * (p0 + (bit >> 3) * W + (bit & 7));
                                 np[0] = nv.x;
                                 np[1] = nv.y;
                                 np[2] = nv.z;
@@ -666,12 +747,15 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                     raster_triangle_into_strip<false>(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, W, r0, r1, keys);
                 else
                     raster_triangle_into_strip<true>(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, W, r0, r1, keys, nplane,
-                                                     Nbase[slot]);
+                                                     FUSED ? post_normal(Nbase[slot]) : Nbase[slot], NSTRIDE);
             }
             __syncthreads();
         }
     }
-    write_strip<BLOCK>(a, b, r0, npix, keys, vx, vy, vz);
+    if (FUSED)
+        write_strip_fused<BLOCK>(a, b, r0, npix, keys);
+    else
+        write_strip<BLOCK>(a, b, r0, npix, keys, vx, vy, vz);
 }
 
 // ---- backward: zeros + scatter-add of g/3 to the z row (render_depth_op.cc:345-363) -------------------------
@@ -750,10 +834,41 @@ size_t fr_render_workspace_bytes_impl(int B, int ntri, int H, int W) {
     return g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes;
 }
 
+template <int BLK, bool FUSED>
+static int launch_resolve(const fr::RenderArgs& a, long long nbins, size_t lds, hipStream_t stream) {
+    static unsigned char ok[64];
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::resolve_write_kernel<BLK, FUSED>), ok) != hipSuccess)
+        return FR_ERR_LAUNCH;
+    hipLaunchKernelGGL((fr::resolve_write_kernel<BLK, FUSED>), dim3((unsigned)nbins), dim3(BLK),
+                       lds + fr::resolve_scratch_bytes(BLK), stream, a);
+    return FR_OK;
+}
+
+static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
+                              int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
+                              const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
+                              hipStream_t stream);
+
 int fr_launch_render_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                              int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
                              float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    return launch_render_impl(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr,
+                              nullptr, nullptr, workspace, ws_bytes, stream);
+}
+
+int fr_launch_rendering_layer(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
+                              int nver, int ntri, int H, int W, int tex_batch, float* net_in, float* depth_img,
+                              float* depth, float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    return launch_render_impl(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, nullptr, nullptr, tri_ind, im_gray,
+                              net_in, depth_img, workspace, ws_bytes, stream);
+}
+
+static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
+                              int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
+                              const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
+                              hipStream_t stream) {
     using namespace fr;
+    const bool fused = net_in != nullptr;
     constexpr int BLOCK = 1024;
     if (nver == 0) ntri = 0;  // no vertex can be valid: every triangle is skipped, the planes are pure background
     if ((size_t)W * sizeof(unsigned long long) > kLdsMax) return FR_ERR_UNSUPPORTED;
@@ -769,11 +884,13 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
     a.tex_stride = (tex_batch == 1) ? 0 : 3ll * nver;
     a.recs = nullptr; a.segoff = nullptr; a.nseg = g.nseg;
     a.recn = nullptr; a.tritex_ws = nullptr;
+    a.im_gray = im_gray; a.net_in = net_in; a.depth_img = depth_img;
     a.wm1 = (float)(W - 1);
     a.hm1 = (float)(H - 1);
     a.rows_magic = g.rows > 1 ? (uint32_t)((0x100000000ull + (unsigned)g.rows - 1) / (unsigned)g.rows) : 0u;
 
     const bool binned = g.binned_ok && ntri > 0 && !env_is("FR_RENDER_IMPL", "scan");
+    if (fused && !binned) return FR_ERR_UNSUPPORTED;  // the caller falls back to the unfused op + elementwise post-processing
     if (!binned) {
         static unsigned char lds_ok[64];
         if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_strip_kernel<BLOCK>), lds_ok) != hipSuccess)
@@ -790,25 +907,14 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
     a.tritex_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes + g.nrm_bytes);
     hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
     const int rblk = env_int("FR_RESOLVE_BLOCK", 512);
-    if (rblk == 256) {
-        static unsigned char ok256[64];
-        if (fr_allow_full_lds(reinterpret_cast<const void*>(&resolve_write_kernel<256>), ok256) != hipSuccess)
-            return FR_ERR_LAUNCH;
-        hipLaunchKernelGGL(resolve_write_kernel<256>, dim3((unsigned)nbins), dim3(256),
-                           g.lds + resolve_scratch_bytes(256), stream, a);
-    } else if (rblk == 512) {
-        static unsigned char ok512[64];
-        if (fr_allow_full_lds(reinterpret_cast<const void*>(&resolve_write_kernel<512>), ok512) != hipSuccess)
-            return FR_ERR_LAUNCH;
-        hipLaunchKernelGGL(resolve_write_kernel<512>, dim3((unsigned)nbins), dim3(512),
-                           g.lds + resolve_scratch_bytes(512), stream, a);
-    } else {
-        static unsigned char ok1024[64];
-        if (fr_allow_full_lds(reinterpret_cast<const void*>(&resolve_write_kernel<1024>), ok1024) != hipSuccess)
-            return FR_ERR_LAUNCH;
-        hipLaunchKernelGGL(resolve_write_kernel<1024>, dim3((unsigned)nbins), dim3(1024),
-                           g.lds + resolve_scratch_bytes(1024), stream, a);
-    }
+    int rc;
+    if (rblk == 256)
+        rc = fused ? launch_resolve<256, true>(a, nbins, g.lds, stream) : launch_resolve<256, false>(a, nbins, g.lds, stream);
+    else if (rblk == 1024)
+        rc = fused ? launch_resolve<1024, true>(a, nbins, g.lds, stream) : launch_resolve<1024, false>(a, nbins, g.lds, stream);
+    else
+        rc = fused ? launch_resolve<512, true>(a, nbins, g.lds, stream) : launch_resolve<512, false>(a, nbins, g.lds, stream);
+    if (rc != FR_OK) return rc;
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 

@@ -175,6 +175,22 @@ class FaceRecNet:
         depthimg_batch = torch.clamp_min(depth, 1e-6)
         return pncc_batch, normalimg_batch, maskimg_batch, depthimg_batch
 
+    def coarse_net_input(self, vertex_proj, triangles=None, colors=None, im_gray=None):
+        """The 7-channel CoarseNet input [maskimg | pncc | normal] (network.py:122) and the depth image, produced by
+        the fused kernel pass (falls back to rendering_layer + concat for shapes it does not cover)."""
+        im_gray = self.im_gray if im_gray is None else im_gray
+        ver = vertex_proj.float()
+        tri = self.tri if triangles is None else torch.as_tensor(triangles, dtype=torch.float32, device=ver.device)
+        tex = self.vertex_code if colors is None else torch.as_tensor(colors, dtype=torch.float32, device=ver.device)
+        if im_gray is None:
+            im_gray = torch.ones((ver.shape[0], self.im_size, self.im_size, 1), dtype=torch.float32, device=ver.device)
+        try:
+            net_in, depth_img, _, _ = _ops().rendering_layer_fused(ver, tri, tex, im_gray)
+        except NotImplementedError:
+            pncc, normal, mask, depth_img = self.rendering_layer(ver, tri, tex, im_gray=im_gray)
+            net_in = torch.cat([mask, pncc, normal], dim=3)
+        return net_in, depth_img
+
     def compute_abedo_image(self, vertices, triangles, abedos, im_gray=None):
         """Albedo (3,N) -> albedo image + normalised normal map through a second render (network.py:394-417)."""
         ver = vertices.float()

@@ -122,6 +122,74 @@ class _RenderDepth(torch.autograd.Function):
         return vertex_grad, None, None, None
 
 
+class _RenderingLayerFused(torch.autograd.Function):
+    """render_depth + the post-processing of FaceRecNet.rendering_layer (nets/network.py:185-199) as one kernel pass:
+    (ver, tri, texture, im_gray) -> (net_input [B,H,W,7], depth_img [B,H,W,1], depth, tri_ind)."""
+
+    @staticmethod
+    def forward(ctx, ver, tri, texture, im_gray):
+        h = _host()
+        image = im_gray
+        _check_forward_shapes(ver, tri, texture, image)
+        ver_c = h.require_gpu_f32(ver, "ver")
+        tri_c = h.require_gpu_f32(tri, "tri")
+        tex_c = h.require_gpu_f32(texture, "texture")
+        img_c = h.require_gpu_f32(im_gray, "im_gray")
+        if img_c.shape[-1] != 1:
+            raise ValueError("im_gray must be [B,H,W,1]")
+        B, H, W = int(img_c.shape[0]), int(img_c.shape[1]), int(img_c.shape[2])
+        nver, ntri = int(ver_c.shape[2]), int(tri_c.shape[1])
+        tex_batch = 1 if tex_c.dim() == 2 else int(tex_c.shape[0])
+        dev = ver_c.device
+        opts = dict(dtype=torch.float32, device=dev)
+        net_in = torch.empty((B, H, W, 7), **opts)
+        depth_img = torch.empty((B, H, W, 1), **opts)
+        depth = torch.empty((B, H, W, 1), **opts)
+        tri_ind = torch.empty((B, H, W, 1), **opts)
+        L = h.lib()
+        with torch.cuda.device(dev):
+            ws_bytes = L.fr_render_depth_workspace_bytes(B, nver, ntri, H, W)
+            ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+            rc = L.fr_rendering_layer_forward(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), h.ptr(img_c), B, nver, ntri, H, W,
+                                              tex_batch, h.ptr(net_in), h.ptr(depth_img), h.ptr(depth), h.ptr(tri_ind),
+                                              h.ptr(ws), ws_bytes, h.stream_ptr(dev))
+        if rc == -4:
+            raise NotImplementedError("fused rendering layer: shape only covered by the fallback rasteriser")
+        h.check(rc, "fr_rendering_layer_forward")
+        ctx.save_for_backward(tri_c, tri_ind, depth, img_c)
+        ctx.dims = (B, nver, ntri, H, W)
+        ctx.mark_non_differentiable(tri_ind)
+        return net_in, depth_img, depth, tri_ind
+
+    @staticmethod
+    def backward(ctx, g_net_in, g_depth_img, g_depth, g_tri_ind):
+        # only the mask channel and the depth image depend on the vertices (through depth, hence vertex z):
+        #   mask = clip(depth, 1e-6, 1) * im  ->  g * im where 1e-6 <= depth <= 1;   depth_img = max(depth, 1e-6)
+        h = _host()
+        tri_c, tri_ind, depth, img = ctx.saved_tensors
+        B, nver, ntri, H, W = ctx.dims
+        dg = torch.zeros_like(depth)
+        if g_net_in is not None:
+            dg = dg + g_net_in[..., 0:1] * img * ((depth >= 1e-6) & (depth <= 1.0)).to(depth.dtype)
+        if g_depth_img is not None:
+            dg = dg + g_depth_img * (depth >= 1e-6).to(depth.dtype)
+        if g_depth is not None:
+            dg = dg + g_depth
+        dg = dg.contiguous()
+        vertex_grad = torch.empty((B, 3, nver), dtype=torch.float32, device=depth.device)
+        with torch.cuda.device(depth.device):
+            rc = h.lib().fr_render_depth_backward(h.ptr(dg), h.ptr(tri_c), h.ptr(tri_ind), h.ptr(vertex_grad), B, nver,
+                                                  ntri, H, W, h.stream_ptr(depth.device))
+        h.check(rc, "fr_render_depth_backward")
+        return vertex_grad, None, None, None
+
+
+def rendering_layer_fused(ver, tri, texture, im_gray):
+    """One-pass rendering layer: returns (net_input [B,H,W,7] = [mask*im | pncc | normal],
+    depth_img, raw depth, tri_ind).  Raises NotImplementedError for shapes only the fallback rasteriser covers."""
+    return _RenderingLayerFused.apply(ver, tri, texture, im_gray)
+
+
 def render_depth(ver, tri, texture, image, **kwargs):
     """Forward function of RenderDepth (reference ops.py:78-81).
 

@@ -54,6 +54,19 @@ int fr_render_depth_forward(const float* vertex, const float* tri, const float* 
                             int ntri, int H, int W, int C, int tex_batch, float* depth, float* tex_img,
                             float* normal, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream);
 
+/* ---- fused rendering layer ------------------------------------------------------------
+ * render_depth + the caller-side post-processing of FaceRecNet.rendering_layer (nets/network.py:185-199) in one
+ * pass, emitting CoarseNet's 7-channel input directly (network.py:122):
+ *   net_input [B,H,W,7] = [ clip(depth,1e-6,1) * im_gray | clip(texture_image,1e-6,1) x3 | n / (sqrt(|n|^2)+1e-6) x3 ]
+ *                         with n flipped to n_z >= 0 and |n|^2 <= 1e-6 replaced by 1
+ *   depth_img [B,H,W,1] = max(depth, 1e-6);  depth [B,H,W,1] and tri_ind [B,H,W,1] as in fr_render_depth_forward
+ *   im_gray   [B,H,W,1].  Same workspace as fr_render_depth_forward.
+ * Returns FR_ERR_UNSUPPORTED for shapes only the fallback rasteriser covers (use the plain op + elementwise ops). */
+int fr_rendering_layer_forward(const float* vertex, const float* tri, const float* texture, const float* im_gray,
+                               int B, int nver, int ntri, int H, int W, int tex_batch, float* net_input,
+                               float* depth_img, float* depth, float* tri_ind, void* workspace, size_t ws_bytes,
+                               void* hip_stream);
+
 /* ---- render_depth backward -----------------------------------------------------------------------------
  * Replaces RenderDepthOpGrad::Compute + functor RenderDepthGrad (render_depth_op.cc:470-528, 325-368;
  * render_depth_op.cu.cc:345-423) reached from the gradient registration at rendering_layer/ops.py:86-95.

@@ -1,0 +1,82 @@
+"""GPU: fr_rendering_layer_forward (render + the post-processing of network.py:185-199 in one pass) against the unfused
+operator followed by the same elementwise formulas in torch, and its gradient against autograd through the unfused
+path."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import net_mod, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(full_assets, synth, B=3, seed=21):
+    net = net_mod().FaceRecNet(mesh_data=full_assets, batch_size=B, im_size=200)
+    P = torch.as_tensor(synth.sample_params_batch(B, beta=0.7, seed=seed), device="cuda:0")
+    V = net.vertices_transform(P)
+    im = torch.rand((B, 200, 200, 1), device="cuda:0")
+    return net, V, im
+
+
+def test_fused_matches_unfused(full_assets, synth):
+    net, V, im = _setup(full_assets, synth)
+    net_in, depth_img, depth, tri_ind = ops().rendering_layer_fused(V, net.tri, net.vertex_code, im)
+    d0, t0, n0, ti0 = ops().render_depth(V, net.tri, net.vertex_code, im.expand(-1, -1, -1, 3))
+    assert torch.equal(depth, d0) and torch.equal(tri_ind, ti0)
+    pncc, normal, mask, dimg = net.rendering_layer(V, net.tri, net.vertex_code, im_gray=im)
+    assert tuple(net_in.shape) == (3, 200, 200, 7)
+    assert torch.equal(net_in[..., 0:1], mask)
+    assert torch.equal(net_in[..., 1:4], pncc)
+    assert torch.equal(depth_img, dimg)
+    # normals: same formula; torch reduces |n|^2 in its own order, so allow 2 ulp
+    assert float((net_in[..., 4:7] - normal).abs().max()) <= 3e-7
+    cov = tri_ind[..., 0] >= 0
+    assert float(net_in[..., 4:7][~cov].abs().max()) == 0.0
+    n2 = (net_in[..., 4:7] ** 2).sum(-1)[cov]
+    assert float((n2 - 1).abs().max()) < 1e-3 and float(net_in[..., 6].min()) >= 0.0
+    # the FaceRecNet helper returns the same tensors
+    ni2, di2 = net.coarse_net_input(V, im_gray=im)
+    assert torch.equal(ni2, net_in) and torch.equal(di2, depth_img)
+
+
+def test_fused_gradient_matches_unfused(full_assets, synth):
+    net, V, im = _setup(full_assets, synth, B=2, seed=5)
+    gw = torch.rand((2, 200, 200, 7), device="cuda:0")
+    gd = torch.rand((2, 200, 200, 1), device="cuda:0")
+    v1 = V.detach().clone().requires_grad_(True)
+    net_in, depth_img, _, _ = ops().rendering_layer_fused(v1, net.tri, net.vertex_code, im)
+    ((net_in * gw).sum() + (depth_img * gd).sum()).backward()
+    v2 = V.detach().clone().requires_grad_(True)
+    pncc, normal, mask, dimg = net.rendering_layer(v2, net.tri, net.vertex_code, im_gray=im)
+    ni = torch.cat([mask, pncc, normal], dim=3)
+    ((ni * gw).sum() + (dimg * gd).sum()).backward()
+    assert float(v1.grad[:, :2].abs().max()) == 0.0
+    assert float(v1.grad.abs().max()) > 0
+    assert torch.allclose(v1.grad, v2.grad, rtol=0, atol=2e-5)
+
+
+def test_fused_small_shapes_and_per_face_texture(oracle):
+    # odd sizes, per-face textures, a shape where big / strip-straddling triangles dominate
+    rs = np.random.RandomState(2)
+    B, nver, ntri, H, W = 3, 120, 260, 33, 47
+    ver = np.empty((B, 3, nver), np.float32)
+    ver[:, 0] = rs.uniform(0, W - 1, (B, nver))
+    ver[:, 1] = rs.uniform(0, H - 1, (B, nver))
+    ver[:, 2] = rs.uniform(0.1, 3, (B, nver))
+    tri = rs.randint(0, nver, (3, ntri)).astype(np.float32)
+    tex = rs.uniform(0, 1, (B, 3, nver)).astype(np.float32)
+    im = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
+    t = lambda a: torch.as_tensor(a, device="cuda:0")  # noqa: E731
+    net_in, depth_img, depth, tri_ind = ops().rendering_layer_fused(t(ver), t(tri), t(tex), t(im))
+    d, tx, n, ti = oracle.render_depth(ver, tri, tex, H, W)
+    np.testing.assert_array_equal(depth.cpu().numpy(), d)
+    np.testing.assert_array_equal(tri_ind.cpu().numpy(), ti)
+    np.testing.assert_array_equal(net_in[..., 1:4].cpu().numpy(), np.clip(tx, np.float32(1e-6), np.float32(1.0)))
+    np.testing.assert_array_equal(net_in[..., 0:1].cpu().numpy(), np.clip(d, np.float32(1e-6), np.float32(1.0)) * im)
+    np.testing.assert_array_equal(depth_img.cpu().numpy(), np.maximum(d, np.float32(1e-6)))
+    nn = n.copy()
+    nn[nn[..., 2] < 0] *= -1.0
+    mag = (nn[..., 0] * nn[..., 0] + nn[..., 1] * nn[..., 1]) + nn[..., 2] * nn[..., 2]
+    mag = np.where(mag > np.float32(1e-6), mag, np.float32(1.0)).astype(np.float32)
+    want = nn / (np.sqrt(mag) + np.float32(1e-6))[..., None]
+    np.testing.assert_array_equal(net_in[..., 4:7].cpu().numpy(), want.astype(np.float32))
