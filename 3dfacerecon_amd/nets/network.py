@@ -126,6 +126,7 @@ class FaceRecNet:
         geo = torch.zeros((batch_size, self.ndim_shape + self.ndim_exp), **f32)
         init_pose = torch.tensor([0, 0, 0, im_size / 2.0, im_size / 2.0, 0, 0.001], **f32)
         self.pred_params = torch.cat([init_pose[None].repeat(batch_size, 1), geo], 1)[:, None, None, :]  # (B,1,1,d)
+        self.init_pred_params = self.pred_params.clone()  # eager callers restart every forward from this constant
 
     # ---- 3DMM decode ----------------------------------------------------------------------------------
     def vertices_transform(self, pred_params, R=None):
