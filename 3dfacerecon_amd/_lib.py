@@ -61,6 +61,9 @@ def _bind(L):
     L.fr_render_depth_forward.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                           ctypes.c_size_t, _vp]
     L.fr_render_depth_forward.restype = _i
+    L.fr_render_depth_forward_phases.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                                                 ctypes.c_size_t, _vp, _i]
+    L.fr_render_depth_forward_phases.restype = _i
     L.fr_rendering_layer_forward.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                              ctypes.c_size_t, _vp]
     L.fr_rendering_layer_forward.restype = _i
@@ -82,7 +85,8 @@ def _bind(L):
 
 EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_render_depth_forward",
            "fr_render_depth_backward", "fr_decode_packed_basis_bytes", "fr_decode_pack_basis", "fr_decode_3dmm",
-           "fr_decode_backward_workspace_bytes", "fr_decode_3dmm_backward", "fr_rendering_layer_forward"]
+           "fr_decode_backward_workspace_bytes", "fr_decode_3dmm_backward", "fr_rendering_layer_forward",
+           "fr_render_depth_forward_phases"]
 
 
 def lib():

@@ -38,6 +38,21 @@ int fr_render_depth_forward(const float* vertex, const float* tri, const float* 
                                     tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream);
 }
 
+int fr_render_depth_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
+                                   int H, int W, int C, int tex_batch, float* depth, float* tex_img, float* normal,
+                                   float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream, int phases) {
+    if (phases < 1 || phases > 3) return FR_ERR_INVALID_ARG;
+    if (B < 0 || nver < 0 || ntri < 0 || H < 0 || W < 0 || C != 3) return FR_ERR_INVALID_ARG;
+    if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
+    if ((size_t)B * H * W == 0) return FR_OK;
+    if (!depth || !tex_img || !normal || !tri_ind) return FR_ERR_INVALID_ARG;
+    if (ntri > 0 && (!tri || (nver > 0 && (!vertex || !texture)))) return FR_ERR_INVALID_ARG;
+    if (ntri >= (1 << 24)) return FR_ERR_UNSUPPORTED;
+    if (ws_bytes < fr_render_depth_workspace_bytes(B, nver, ntri, H, W)) return FR_ERR_WORKSPACE;
+    return fr_launch_render_forward_phases(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal,
+                                           tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream, phases);
+}
+
 int fr_rendering_layer_forward(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
                                int nver, int ntri, int H, int W, int tex_batch, float* net_input, float* depth_img,
                                float* depth, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream) {

@@ -95,6 +95,9 @@ inline hipError_t fr_allow_full_lds(const void* kernel, unsigned char* done /*[6
 int fr_launch_render_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                              int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
                              float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream);
+int fr_launch_render_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
+                                    int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
+                                    float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases);
 int fr_launch_rendering_layer(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
                               int nver, int ntri, int H, int W, int tex_batch, float* net_in, float* depth_img,
                               float* depth, float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream);

@@ -847,13 +847,21 @@ static int launch_resolve(const fr::RenderArgs& a, long long nbins, size_t lds, 
 static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
                               int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
                               const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
-                              hipStream_t stream);
+                              hipStream_t stream, int phases = 3);
 
 int fr_launch_render_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                              int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
                              float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream) {
     return launch_render_impl(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr,
                               nullptr, nullptr, workspace, ws_bytes, stream);
+}
+
+// profiling aid: launch only the emit kernel (phases = 1) or only the resolve kernel (phases = 2) of the forward op
+int fr_launch_render_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
+                                    int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
+                                    float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases) {
+    return launch_render_impl(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr,
+                              nullptr, nullptr, workspace, ws_bytes, stream, phases);
 }
 
 int fr_launch_rendering_layer(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
@@ -866,7 +874,7 @@ int fr_launch_rendering_layer(const float* vertex, const float* tri, const float
 static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
                               int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
                               const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
-                              hipStream_t stream) {
+                              hipStream_t stream, int phases) {
     using namespace fr;
     const bool fused = net_in != nullptr;
     constexpr int BLOCK = 1024;
@@ -892,6 +900,7 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     const bool binned = g.binned_ok && ntri > 0 && !env_is("FR_RENDER_IMPL", "scan");
     if (fused && !binned) return FR_ERR_UNSUPPORTED;  // the caller falls back to the unfused op + elementwise post-processing
     if (!binned) {
+        if (!(phases & 2)) return FR_OK;  // the fallback is a single kernel: it counts as the resolve phase
         static unsigned char lds_ok[64];
         if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_strip_kernel<BLOCK>), lds_ok) != hipSuccess)
             return FR_ERR_LAUNCH;
@@ -905,7 +914,9 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     a.segoff = reinterpret_cast<uint16_t*>(wsp + g.recs_bytes);
     a.recn = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes);
     a.tritex_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes + g.nrm_bytes);
-    hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
+    if (phases & 1)
+        hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
+    if (!(phases & 2)) return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
     const int rblk = env_int("FR_RESOLVE_BLOCK", 512);
     int rc;
     if (rblk == 256)

@@ -80,6 +80,12 @@ class DecodeRenderPlan:
         if rc:
             self._h.check(rc, "fr_render_depth_forward")
 
+    def render_phase(self, phases):
+        """Profiling aid: phases = 1 launches only raster_emit_kernel, 2 only resolve_write_kernel."""
+        rc = self._L.fr_render_depth_forward_phases(*self._ren_args, self._stream(), int(phases))
+        if rc:
+            self._h.check(rc, "fr_render_depth_forward_phases")
+
     def outputs(self):
         return self.depth, self.texture_image, self.normal, self.tri_ind
 

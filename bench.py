@@ -132,7 +132,7 @@ def main():
     # EV_EVERY-th step only: an event pair costs a few microseconds of stream bubble, which at ~160 us per step would
     # otherwise tax every step by ~7 %.
     EV_EVERY = 8
-    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in range(0, K, EV_EVERY)}
+    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for k in range(0, K, EV_EVERY)}
     dist_u.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -141,18 +141,21 @@ def main():
         if e is None:
             plan.decode()
             plan.render()
-        else:
+        else:  # same three kernels, each bracketed by events (the render op launched phase by phase)
             e[0].record()
             plan.decode()
             e[1].record()
-            plan.render()
+            plan.render_phase(1)
             e[2].record()
+            plan.render_phase(2)
+            e[3].record()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     dist_u.barrier()
     elapsed = dist_u.max_over_ranks(t1 - t0, device=dev)
     decode_ms = sum(e[0].elapsed_time(e[1]) for e in ev.values()) / len(ev)
-    render_ms = sum(e[1].elapsed_time(e[2]) for e in ev.values()) / len(ev)
+    emit_ms = sum(e[1].elapsed_time(e[2]) for e in ev.values()) / len(ev)
+    resolve_ms = sum(e[2].elapsed_time(e[3]) for e in ev.values()) / len(ev)
     cov = float((plan.tri_ind >= 0).float().mean().item())
 
     graph_fps = None
@@ -172,28 +175,41 @@ def main():
         ab = algorithmic_bytes(N, T, Kc, H, W, B)
         value = world * B * K / elapsed
         flops = 2.0 * 3 * N * Kc * B
-        roof_render = {"bound": "hbm", "kernel": "fr_render_depth_forward = raster_emit_kernel + resolve_write_kernel",
-                       "achieved": ab["render"] * B / (render_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "traffic": None, "avg_ms": render_ms}
-        roof_decode = {"bound": "mfma", "kernel": "fr_decode_3dmm = decode_kernel<2>",
+        # algorithmic bytes of the render op (1,948,403 B/face) split over its two kernels: the emit kernel
+        # owns the vertex / triangle / texture reads, the resolve kernel the four output planes
+        emit_bytes = (4.0 * 3 * N + (4.0 * 3 * T + 4.0 * 3 * N) / B) * B
+        resolve_bytes = 4.0 * H * W * 8 * B
+        roof_decode = {"bound": "mfma", "kernel": "decode_kernel<2,16> (fr_decode_3dmm)",
                        "achieved": flops / (decode_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "traffic": None, "avg_ms": decode_ms,
+                       "traffic": None, "avg_ms": decode_ms, "algorithmic_flop_per_launch": flops,
                        "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9}
+        roof_emit = {"bound": "hbm", "kernel": "raster_emit_kernel (fr_render_depth_forward, phase 1)",
+                     "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "traffic": None, "avg_ms": emit_ms, "algorithmic_bytes_per_launch": emit_bytes}
+        roof_resolve = {"bound": "hbm", "kernel": "resolve_write_kernel<512> (fr_render_depth_forward, phase 2)",
+                        "achieved": resolve_bytes / (resolve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "traffic": None, "avg_ms": resolve_ms, "algorithmic_bytes_per_launch": resolve_bytes}
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json:
         # FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 correction applied as the microarch guide says)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pmc.get("batch") == B and (H, W) == (200, 200):
-                roof_render["traffic"] = pmc["render_bytes_per_launch"]
                 roof_decode["traffic"] = pmc["decode_bytes_per_launch"]
-                roof_render["traffic_source"] = roof_decode["traffic_source"] = "profiles/pmc_traffic.json"
+                roof_emit["traffic"] = pmc["render_split"]["raster_emit_kernel"]
+                roof_resolve["traffic"] = pmc["render_split"]["resolve_write_kernel"]
+                for r in (roof_decode, roof_emit, roof_resolve):
+                    r["traffic_source"] = "profiles/pmc_traffic.json"
         except (OSError, ValueError, KeyError):
             pass
-        for r in (roof_render, roof_decode):
+        kernels = {"decode": roof_decode, "raster_emit": roof_emit, "resolve_write": roof_resolve}
+        for r in kernels.values():
             r["frac"] = r["achieved"] / r["peak"]
-            r["algorithmic_bytes_per_launch" if r["bound"] == "hbm" else "algorithmic_flop_per_launch"] = \
-                ab["render"] * B if r["bound"] == "hbm" else flops
-        dominant = roof_render if render_ms >= decode_ms else roof_decode
+        dominant = max(kernels.values(), key=lambda r: r["avg_ms"])  # the kernel with the longest average launch
+        render_ms = emit_ms + resolve_ms
+        kernels["render_op"] = {"bound": "hbm", "kernel": "fr_render_depth_forward (both kernels)", "avg_ms": render_ms,
+                                "achieved": ab["render"] * B / (render_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": ab["render"] * B / (render_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_launch": ab["render"] * B}
         out = {
             "metric": "faces/sec (3DMM decode+depth render), batch 64 @200x200",
             "value": value, "unit": "faces/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -205,7 +221,7 @@ def main():
                        "sampler": "sample_test.py:23-38 beta=0.7 seed=3456+rank", "coverage": cov,
                        "sharding": "batch over ranks, no data-path collective"},
             "roofline": dominant,
-            "kernels": {"decode": roof_decode, "render": roof_render},
+            "kernels": kernels,
             "pipeline_hbm": {"bytes_per_face": ab["pipeline"],
                              "achieved_GBs": ab["pipeline"] * value / world / 1e9,
                              "frac_of_8TBs": ab["pipeline"] * value / world / 1e9 / HBM_PEAK_GBS},

@@ -54,6 +54,15 @@ int fr_render_depth_forward(const float* vertex, const float* tri, const float* 
                             int ntri, int H, int W, int C, int tex_batch, float* depth, float* tex_img,
                             float* normal, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream);
 
+/* Profiling aid: the forward op is two kernels (raster_emit_kernel writes per-strip hit records into the workspace,
+ * resolve_write_kernel turns them into the four planes).  phases = 1 launches only the first, 2 only the second
+ * (it consumes whatever records the workspace holds), 3 both (== fr_render_depth_forward).  bench.py uses it to bracket
+ * each kernel with HIP events inside the timed region. */
+int fr_render_depth_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver,
+                                   int ntri, int H, int W, int C, int tex_batch, float* depth, float* tex_img,
+                                   float* normal, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream,
+                                   int phases);
+
 /* ---- fused rendering layer ------------------------------------------------------------
  * render_depth + the caller-side post-processing of FaceRecNet.rendering_layer (nets/network.py:185-199) in one
  * pass, emitting CoarseNet's 7-channel input directly (network.py:122):
