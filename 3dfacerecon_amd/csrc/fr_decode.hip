@@ -154,6 +154,28 @@ __device__ __forceinline__ void mfma_group1(float4 a0, const float* Plg, f32x4 (
     mfma_step<NBW>(a0.w, ldb<NBW>(Plg, 3), acc0);
 }
 
+// Work distribution shared by the decode kernels.  A workgroup works on `slots` tiles at a time (slot = wave / halves).
+// Tiles are dealt in adjacent PAIRS: slots 2s and 2s+1 of a workgroup take tiles 2P and 2P+1, so the two 64-byte pieces
+// a pair writes into each output row come from one CU at about the same time; pair P goes to workgroup perm(P % grid) of
+// round P / grid, where perm keeps consecutive pairs on the same XCD (workgroup b runs on XCD b % 8), so the partial
+// cache lines at the seams still meet in one L2.  Dealing pairs round-robin keeps the last, partial round to at most one
+// extra pair per CU.
+struct TileWalk {
+    int first, stride;
+};
+__device__ __forceinline__ TileWalk tile_walk(int slot, int slots, int b, int grid) {
+    const int pb = (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b;
+    TileWalk w;
+    if (slots & 1) {  // odd slot count (not used by the launchers): plain round-robin over tiles
+        w.first = slot * grid + pb;
+        w.stride = slots * grid;
+    } else {
+        w.first = 2 * ((slot >> 1) * grid + pb) + (slot & 1);
+        w.stride = slots * grid;  // = 2 * (slots / 2) * grid
+    }
+    return w;
+}
+
 // Persistent kernel: one workgroup per CU (16 waves).  The parameters are laid into LDS once per CU; then every wave
 // walks work items (tile of 16 vertices, group of NBW batch-column blocks).  With B = 64 an item is half a tile
 // (NBW = 2): 6,652 items over 1,024 SIMDs balance to within 8 % of the MFMA floor, where whole tiles (3,326) would leave
@@ -162,19 +184,10 @@ __device__ __forceinline__ void mfma_group1(float4 a0, const float* Plg, f32x4 (
 //
 // LDS image of the parameters (B operand), per half hf: P[hf][k][j][NBW] floats -- lane l of k-step s reads the NBW
 // consecutive floats at (s*64 + l)*NBW, i.e. one conflict-free ds_read_b32/b64 per k-step.
-template <int NBW, int DEC_WAVES>
-__global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
-    constexpr int DEC_BLOCK = DEC_WAVES * 64;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int GS = groups_of(a.ns), GE = groups_of(a.ne), G = GS + GE;
-    const int KP = G * KGROUP;                      // padded coefficient count
-    const size_t half_floats = (size_t)KP * 16 * NBW;
-    float* Mt = smem + (size_t)KP * 16 * 4;          // [64][12] after the 4 column blocks' parameters
-    double* SC = reinterpret_cast<double*>(Mt + 64 * 12);  // [64][3][2] sin/cos of the pose angles
-    const int tid = threadIdx.x;
-    const int nd = FR_N_POSE + a.ns + a.ne;
-    const int nbatch = min(a.B - a.b0, 64);
-
+// Per-CU prologue shared by the decode kernels: the parameters go to LDS in B-fragment order, the pose to Mt = f.R | t3d.
+template <int NBW, int DEC_BLOCK>
+__device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem, float* Mt, double* SC, int GS, int GE,
+                                                size_t half_floats, int tid, int nd, int nbatch) {
     // parameters -> LDS in B-fragment order: TPR threads per batch row, each walks the row with stride
     // TPR; loads are unconditional (clamped) and batched so they pipeline; padding slots and absent rows are 0.
     {
@@ -245,17 +258,76 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
     }
     __syncthreads();
 
+}
+
+// Fused epilogue of one work item: 3x3 (f.R) transform, +t3d, y flip, store [B,3,N].
+template <int NBW>
+__device__ __forceinline__ void decode_store(const DecodeArgs& a, const f32x4 (&s0)[NBW], const f32x4 (&s1)[NBW],
+                                             const f32x4 (&s2)[NBW], const float* Mt, int tile, int hf, int lane,
+                                             int nbatch, int N) {
+    const int p0v = tile * TILE_V + 4 * (lane >> 4);  // first of this lane's 4 vertices
+#pragma unroll
+    for (int nb = 0; nb < NBW; nb++) {
+        const int bb = 16 * (hf * NBW + nb) + (lane & 15);
+        if (bb >= nbatch) continue;
+        const float* m = Mt + bb * 12;
+        f32x4 px, py, pz;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float vx = s0[nb][r], vy = s1[nb][r], vz = s2[nb][r];
+            const float qx = __builtin_fmaf(m[2], vz, __builtin_fmaf(m[1], vy, m[0] * vx)) + m[9];
+            const float qy = __builtin_fmaf(m[5], vz, __builtin_fmaf(m[4], vy, m[3] * vx)) + m[10];
+            const float qz = __builtin_fmaf(m[8], vz, __builtin_fmaf(m[7], vy, m[6] * vx)) + m[11];
+            px[r] = qx;
+            py[r] = (a.im_size - qy) - 1.0f;  // network.py:168
+            pz[r] = qz;
+        }
+        float* ox = a.out + ((size_t)(a.b0 + bb) * 3) * N + p0v;
+        float* oy = ox + N;
+        float* oz = oy + N;
+        if (p0v + 3 < N) {
+            *reinterpret_cast<f32x4u*>(ox) = px;
+            *reinterpret_cast<f32x4u*>(oy) = py;
+            *reinterpret_cast<f32x4u*>(oz) = pz;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (p0v + r < N) {
+                    ox[r] = px[r];
+                    oy[r] = py[r];
+                    oz[r] = pz[r];
+                }
+            }
+        }
+    }
+}
+
+template <int NBW, int DEC_WAVES>
+__global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
+    constexpr int DEC_BLOCK = DEC_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int GS = groups_of(a.ns), GE = groups_of(a.ne), G = GS + GE;
+    const int KP = G * KGROUP;                      // padded coefficient count
+    const size_t half_floats = (size_t)KP * 16 * NBW;
+    float* Mt = smem + (size_t)KP * 16 * 4;          // [64][12] after the 4 column blocks' parameters
+    double* SC = reinterpret_cast<double*>(Mt + 64 * 12);  // [64][3][2] sin/cos of the pose angles
+    const int tid = threadIdx.x;
+    const int nd = FR_N_POSE + a.ns + a.ne;
+    const int nbatch = min(a.B - a.b0, 64);
+
+    decode_prologue<NBW, DEC_BLOCK>(a, smem, Mt, SC, GS, GE, half_floats, tid, nd, nbatch);
+
     const int lane = tid & 63, wave = tid >> 6;
     const int tiles = tiles_of(a.N);
     const int N = a.N;
     // Work distribution: a tile's column-block halves go to neighbouring waves of one workgroup (they stream the same A
-    // fragments at the same time, so the second read is an L1/L2 hit); tiles are dealt round-robin over the
-    // workgroups so that the last, partial round leaves at most one extra tile per CU.
+    // fragments at the same time, so the second read is an L1/L2 hit); tiles are dealt as tile_walk describes.
     const int H2 = a.halves;              // 1 or 2
     const int slots = DEC_WAVES / H2;     // tiles a workgroup works on at a time
     const int slot = wave / H2;
     const int hf = wave - slot * H2;
-    for (int tile = slot * gridDim.x + blockIdx.x; tile < tiles; tile += slots * gridDim.x) {
+    const TileWalk tw = tile_walk(slot, slots, (int)blockIdx.x, (int)gridDim.x);
+    for (int tile = tw.first; tile < tiles; tile += tw.stride) {
         const float4* Ap = a.A + (size_t)tile * G * 3 * 64 + lane;   // group g, coordinate c at Ap[(g*3+c)*64]
         const float* Pll = smem + (size_t)hf * half_floats + (size_t)lane * NBW;  // this lane's B fragment, k-step 0
         f32x4 s0[NBW], s1[NBW], s2[NBW];
@@ -310,43 +382,151 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
 #pragma unroll
             for (int nb = 0; nb < NBW; nb++) s2[nb] = s2[nb] + e[nb];
         }
-        // ---- fused epilogue: 3x3 (f.R) transform, +t3d, y flip, store [B,3,N] ----
-        const int p0v = tile * TILE_V + 4 * (lane >> 4);  // first of this lane's 4 vertices
+        decode_store<NBW>(a, s0, s1, s2, Mt, tile, hf, lane, nbatch, N);
+    }
+}
+
+
+// ---- streaming variant for a compile-time basis shape ---------------------------------------------------------------
+// Same arithmetic as decode_kernel, different schedule.  With the group counts known at compile time (the model's
+// 199 + 29 coefficients are 13 + 2 groups) an item is a fixed sequence of F = 3*(G+1) A fragments (g-major, coordinate
+// minor; the last three are the item's mu values).  A wave treats ALL of its items as one fragment stream that runs
+// through a ring of R float4 registers: fragment i is consumed from slot i % R and the slot is immediately re-requested
+// with fragment i + R -- of the next item when the current one runs out, so the pipeline is never refilled per item
+// and every fragment is requested R fragments (R/3 groups, ~8*R*NBW MFMAs of this wave and ~4x that of the SIMD)
+// before its MFMAs issue.  F % R == 0 keeps the slot assignment identical for every item, so the item body is fully
+// unrolled straight-line code with no cursor branches.  The requests are inline asm so that the compiler can neither
+// reorder them nor drain them with its own vmcnt(0); the only waits are the counted s_waitcnt vmcnt(R-1) on the oldest
+// slot (FR_RING_WAIT ties the slot register to the wait).
+#ifndef FR_PROBE_DECODE
+#define FR_PROBE_DECODE 0  // development probes (tools/decode_probe.hip): 1 = no MFMA, 2 = requests hit 256 tiles, 4 = no prologue, 8 = no A requests, 16 = no LDS B reads, 32 = (almost) no stores
+#endif
+#define FR_RING_LD(dst, sbase, voff) \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase))
+
+template <int R>
+__device__ __forceinline__ void ring_wait(f32x4& slot) {
+    static_assert(R == 6 || R == 8 || R == 12, "ring size");
+    if constexpr (R == 6) asm volatile("s_waitcnt vmcnt(5)" : "+v"(slot));
+    else if constexpr (R == 8) asm volatile("s_waitcnt vmcnt(7)" : "+v"(slot));
+    else asm volatile("s_waitcnt vmcnt(11)" : "+v"(slot));
+}
+
+template <int GS, int GE, int R, int NBW, int DEC_WAVES>
+__global__ __launch_bounds__(DEC_WAVES * 64) void decode_ring_kernel(DecodeArgs a) {
+    constexpr int DEC_BLOCK = DEC_WAVES * 64;
+    constexpr int G = GS + GE;
+    constexpr int F = 3 * (G + 1);  // fragments per item
+    static_assert(F % R == 0, "the ring must close on an item boundary");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = G * KGROUP;
+    constexpr size_t half_floats = (size_t)KP * 16 * NBW;
+    float* Mt = smem + (size_t)KP * 16 * 4;
+    double* SC = reinterpret_cast<double*>(Mt + 64 * 12);
+    const int tid = threadIdx.x;
+    const int nd = FR_N_POSE + a.ns + a.ne;
+    const int nbatch = min(a.B - a.b0, 64);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = tiles_of(a.N);
+    const int N = a.N;
+    const int H2 = a.halves;
+    const int slots = DEC_WAVES / H2;
+    const int slot = wave / H2;
+    const int hf = wave - slot * H2;
+    const TileWalk tw = tile_walk(slot, slots, (int)blockIdx.x, (int)gridDim.x);
+    const int tile0 = tw.first, tstride = tw.stride;
+    const float* Pll = smem + (size_t)hf * half_floats + (size_t)lane * NBW;
+    const unsigned voffA = (unsigned)lane * 16u;         // this lane's 16 bytes of a 1 KiB A fragment
+    const unsigned voffM = (unsigned)(lane >> 4) * 16u;  // this lane's 4 vertices of a 64-byte mu row
+    const char* Ab = reinterpret_cast<const char*>(a.A);
+    const char* Mb = reinterpret_cast<const char*>(a.mu_p);
+    constexpr size_t tile_bytes = (size_t)G * 3 * 1024;
+
+    f32x4 ring[R];
+    // fragment f (0..F-1) of tile t
+#define FR_REQ(slot_, f_, t_)                                                                        \
+    {                                                                                                \
+        if ((f_) < 3 * G) {                                                                          \
+            const char* sb_ = Ab + (size_t)((FR_PROBE_DECODE & 2) ? (t_) & 255 : (t_)) * tile_bytes + (size_t)(f_) * 1024; \
+            FR_RING_LD(ring[slot_], sb_, voffA);                                                     \
+        } else {                                                                                     \
+            const char* sb_ = Mb + (size_t)(t_) * (3 * TILE_V * 4) + (size_t)((f_) - 3 * G) * (TILE_V * 4); \
+            FR_RING_LD(ring[slot_], sb_, voffM);                                                     \
+        }                                                                                            \
+    }
+    // the first R fragments are requested before the per-CU prologue, so their HBM latency overlaps the parameter staging
+    // (a wave without work requests tile 0 and drops it)
+    {
+        const int t0c = tile0 < tiles ? tile0 : 0;
 #pragma unroll
-        for (int nb = 0; nb < NBW; nb++) {
-            const int bb = 16 * (hf * NBW + nb) + (lane & 15);
-            if (bb >= nbatch) continue;
-            const float* m = Mt + bb * 12;
-            f32x4 px, py, pz;
+        for (int f = 0; f < R; f++) FR_REQ(f, f, t0c)
+    }
+    if constexpr (!(FR_PROBE_DECODE & 4)) decode_prologue<NBW, DEC_BLOCK>(a, smem, Mt, SC, GS, GE, half_floats, tid, nd, nbatch);
+    if (tile0 >= tiles) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float vx = s0[nb][r], vy = s1[nb][r], vz = s2[nb][r];
-                const float qx = __builtin_fmaf(m[2], vz, __builtin_fmaf(m[1], vy, m[0] * vx)) + m[9];
-                const float qy = __builtin_fmaf(m[5], vz, __builtin_fmaf(m[4], vy, m[3] * vx)) + m[10];
-                const float qz = __builtin_fmaf(m[8], vz, __builtin_fmaf(m[7], vy, m[6] * vx)) + m[11];
-                px[r] = qx;
-                py[r] = (a.im_size - qy) - 1.0f;  // network.py:168
-                pz[r] = qz;
-            }
-            float* ox = a.out + ((size_t)(a.b0 + bb) * 3) * N + p0v;
-            float* oy = ox + N;
-            float* oz = oy + N;
-            if (p0v + 3 < N) {
-                *reinterpret_cast<f32x4u*>(ox) = px;
-                *reinterpret_cast<f32x4u*>(oy) = py;
-                *reinterpret_cast<f32x4u*>(oz) = pz;
-            } else {
+        for (int f = 0; f < R; f++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[f]));
+        return;
+    }
+    f32x4 c[3][NBW], sv[3][NBW];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (p0v + r < N) {
-                        ox[r] = px[r];
-                        oy[r] = py[r];
-                        oz[r] = pz[r];
+    for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+        for (int nb = 0; nb < NBW; nb++) c[cc][nb] = sv[cc][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int ct = tile0; ct < tiles; ct += tstride) {
+        int nt = ct + tstride;  // tile whose fragments are requested once this item's run out
+        if (nt >= tiles) nt = tile0;  // past the end: harmless re-request of a valid address, never consumed
+        typename BFrag<NBW>::type bq[4];
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            const int g = f / 3, cc = f % 3;
+            if constexpr (!(FR_PROBE_DECODE & 8)) ring_wait<R>(ring[f % R]);
+            if (f < 3 * G) {
+                if (cc == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if ((FR_PROBE_DECODE & 16) == 0 || (ct == tile0 && g == 0)) bq[j] = ldb<NBW>(Pll + (size_t)g * 256 * NBW, j);
+                    if (g == GS) {  // S finished: park it, restart the fmaf chain from +0 for E
+#pragma unroll
+                        for (int c2 = 0; c2 < 3; c2++)
+#pragma unroll
+                            for (int nb = 0; nb < NBW; nb++) {
+                                sv[c2][nb] = c[c2][nb];
+                                c[c2][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
                     }
                 }
+                const f32x4 af = ring[f % R];
+                if constexpr (FR_PROBE_DECODE & 1) {
+                    c[cc][0] += af;
+                } else {
+                    mfma_step<NBW>(af.x, bq[0], c[cc]);
+                    mfma_step<NBW>(af.y, bq[1], c[cc]);
+                    mfma_step<NBW>(af.z, bq[2], c[cc]);
+                    mfma_step<NBW>(af.w, bq[3], c[cc]);
+                }
+            } else {  // mu fragment of coordinate cc: v = (mu + S) + E   (network.py:159)
+                const f32x4 m = ring[f % R];
+#pragma unroll
+                for (int nb = 0; nb < NBW; nb++) c[cc][nb] = (m + sv[cc][nb]) + c[cc][nb];
+            }
+            // re-request the slot: fragment f + R of this item, or of the next one
+            if constexpr (!(FR_PROBE_DECODE & 8)) {
+                if (f + R < F) FR_REQ(f % R, f + R, ct)
+                else FR_REQ(f % R, f + R - F, nt)
             }
         }
+        if ((FR_PROBE_DECODE & 32) == 0 || c[0][0][0] + c[1][0][1] + c[2][NBW - 1][2] == 12345.678f)
+            decode_store<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+            for (int nb = 0; nb < NBW; nb++) c[cc][nb] = sv[cc][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int f = 0; f < R; f++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[f]));
+#undef FR_REQ
 }
 
 }  // namespace fr
@@ -394,6 +574,18 @@ static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int cus, size_
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
+template <int GS, int GE, int R, int NBW, int WAVES>
+static int launch_decode_ring(const fr::DecodeArgs& a, size_t lds, int cus, size_t tiles, hipStream_t stream) {
+    static unsigned char lds_ok[64];
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES>), lds_ok) !=
+        hipSuccess)
+        return FR_ERR_LAUNCH;
+    const int slots = WAVES / a.halves;
+    const int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
+    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
+}
+
 int fr_launch_decode(const float* params, const void* packed, const float* R_override, int B, int N, int n_shape,
                      int n_exp, float im_size, float* vertex_proj, hipStream_t stream) {
     using namespace fr;
@@ -418,7 +610,17 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
         int nbw = nbt == 1 ? 1 : 2;                     // column blocks per work item
         if (nbw_env == 4 && nbt > 2) nbw = 4;
         a.halves = (nbt + nbw - 1) / nbw;
-        int rc = nbw == 1   ? launch_decode_nbw<1, 16>(a, lds, cus, tiles, stream)
+        // the model's own basis shape (199 + 29 coefficients = 13 + 2 groups) takes the fully unrolled ring schedule
+        static const bool loop_env = getenv("FR_DECODE_IMPL") && !strcmp(getenv("FR_DECODE_IMPL"), "loop");
+        static const int ring_env = getenv("FR_DECODE_RING") ? atoi(getenv("FR_DECODE_RING")) : 8;
+        const bool ring = !loop_env && groups_of(n_shape) == 13 && groups_of(n_exp) == 2 && nbw <= 2;
+        int rc;
+        if (ring && nbw == 1) rc = launch_decode_ring<13, 2, 8, 1, 16>(a, lds, cus, tiles, stream);
+        else if (ring && ring_env == 6) rc = launch_decode_ring<13, 2, 6, 2, 16>(a, lds, cus, tiles, stream);
+        else if (ring && ring_env == 12) rc = launch_decode_ring<13, 2, 12, 2, 16>(a, lds, cus, tiles, stream);
+        else if (ring) rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);
+        else
+            rc = nbw == 1   ? launch_decode_nbw<1, 16>(a, lds, cus, tiles, stream)
                  : nbw == 2 ? launch_decode_nbw<2, 16>(a, lds, cus, tiles, stream)
                             : launch_decode_nbw<4, 12>(a, lds, cus, tiles, stream);
         if (rc != FR_OK) return rc;
