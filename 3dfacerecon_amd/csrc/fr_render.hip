@@ -59,7 +59,8 @@ struct RenderArgs {
     uint32_t rows_magic;   // ceil(2^32 / rows): y / rows == umulhi(y, magic) for y, rows < 2^16
 };
 
-constexpr int SEG = 512;         // triangles (and record capacity) per segment
+constexpr int SEG = 504;         // triangles (and record capacity) per segment: 504 * 40 B of queue + counters <= 20 KiB,
+                                 // so eight emit workgroups share a CU's 160 KiB of LDS (8 waves per SIMD)
 constexpr int OFF_STRIDE = 64;   // u16 offsets per segment (strips + 1 <= 64)
 constexpr int MAX_STRIPS = OFF_STRIDE - 1;
 constexpr int SMALL_W = 8, SMALL_H = 4;  // hit-mask window: bit = dy*8 + dx
@@ -420,11 +421,11 @@ __device__ __forceinline__ bool id_ok(float f, int n, int& p) {
 // normal, record emission) on DENSE waves -- about half as many wave-instructions -- and parks the records in LDS.
 // Phase C counting-sorts them by strip and writes them out.
 constexpr int EMIT_BLOCK = 256;
-constexpr int TPT = SEG / EMIT_BLOCK;  // triangles per thread in phase A
+constexpr int TPT = 2;                 // triangles per thread in phase A
+constexpr int EMIT_ACTIVE = SEG / TPT; // threads that own triangles in phase A (252 of 256)
 
 __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
-    __shared__ uint32_t cnt[OFF_STRIDE];
-    __shared__ uint32_t base[OFF_STRIDE];
+    __shared__ uint32_t cnt[OFF_STRIDE];  // per-bucket record count; turned into the bucket's start offset in phase C
     __shared__ uint32_t qn;
     __shared__ float4 qa[SEG];   // phase A->B: x1 y1 x2 y2          phase B->C: the record
     __shared__ float4 qb[SEG];   // phase A->B: x3 y3 z1 z2          phase B->C: the record's normal
@@ -452,13 +453,13 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
         bool valid[TPT];
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
-            const int t = seg * SEG + u * EMIT_BLOCK + tid;
+            const int t = seg * SEG + u * EMIT_ACTIVE + tid;
             const uint32_t tt = (uint32_t)min(t, ntri - 1);
             const bool ok1 = id_ok(ld_off(a.tri, tt), nver, p1[u]);
             const bool ok2 = id_ok(ld_off(a.tri + ntri, tt), nver, p2[u]);
             const bool ok3 = id_ok(ld_off(a.tri + 2 * (size_t)ntri, tt), nver, p3[u]);
             // (ids outside [0,nver) -> deviation 3: the reference would read out of bounds)
-            valid[u] = (t < ntri) && ok1 && ok2 && ok3;
+            valid[u] = (tid < EMIT_ACTIVE) && (t < ntri) && ok1 && ok2 && ok3;
             if (!valid[u]) p1[u] = p2[u] = p3[u] = 0;  // nver >= 1 here: safe dummy gathers
         }
 #pragma unroll
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
                     const float* tj = a.texture + (size_t)j * nver;
                     tm[j] = ((ld_off(tj, p1[u]) + ld_off(tj, p2[u])) + ld_off(tj, p3[u])) / 3.0f;
                 }
-                a.tritex_ws[seg * SEG + u * EMIT_BLOCK + tid] = make_float4(tm[0], tm[1], tm[2], 0.0f);
+                a.tritex_ws[seg * SEG + u * EMIT_ACTIVE + tid] = make_float4(tm[0], tm[1], tm[2], 0.0f);
             }
         }
 #pragma unroll
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
                 const uint32_t slot = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 qa[slot] = make_float4(x1[u], y1[u], x2[u], y2[u]);
                 qb[slot] = make_float4(x3[u], y3[u], z1[u], z2[u]);
-                qd[slot] = make_uint2(__float_as_uint(z3[u]), (uint32_t)(u * EMIT_BLOCK + tid));
+                qd[slot] = make_uint2(__float_as_uint(z3[u]), (uint32_t)(u * EMIT_ACTIVE + tid));
             }
         }
     }
@@ -532,9 +533,13 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             if (x_max - x_min < SMALL_W && y_max - y_min < SMALL_H && s0 == s1) {
                 const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
                 uint32_t m = 0;
-                for (int y = y_min; y <= y_max; y++)
-                    for (int x = x_min; x <= x_max; x++)
-                        if (point_in_tri(ts, x, y)) m |= 1u << ((y - y_min) * SMALL_W + (x - x_min));
+                const int bw = x_max - x_min + 1, npx = bw * (y_max - y_min + 1);
+                int dx = 0, bit = 0, yy = y_min;
+#pragma clang loop unroll(disable)
+                for (int k = 0; k < npx; k++) {
+                    if (point_in_tri(ts, x_min + dx, yy)) m |= 1u << (bit + dx);
+                    if (++dx == bw) { dx = 0; bit += SMALL_W; yy++; }
+                }
                 rec.w = m;
                 emit = (m != 0);
                 bucket = 1 + s0;
@@ -579,8 +584,9 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     if (tid == 0) {
         uint32_t run = 0;
         for (int k = 0; k <= S; k++) {
-            base[k] = run;
-            run += cnt[k];
+            const uint32_t c = cnt[k];
+            cnt[k] = run;  // start of bucket k
+            run += c;
             off[k] = (uint16_t)run;  // off[0] = #big, off[s+1] = end of strip s
         }
     }
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
         const uint32_t tag = qd[sl].x;
         if (tag != 0xFFFFFFFFu) {
             const float4 r = qa[sl];
-            const uint32_t slot = base[tag >> 16] + (tag & 0xFFFFu);
+            const uint32_t slot = cnt[tag >> 16] + (tag & 0xFFFFu);
             R[slot] = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
             Rn[slot] = qb[sl];
         }

@@ -53,9 +53,10 @@ def test_validation_codes_without_gpu():
     assert L.fr_decode_3dmm(nul, nul, nul, 0, 10, 2, 2, 200.0, nul, nul) == 0
     # binned rasteriser workspace: 16-byte hit records (one slot per triangle) + 64 u16 bucket offsets per segment
     # + per-record normals (float4, same slots) + texture-mean table (float4 per triangle, same bound)
-    nseg = (105840 + 511) // 512
+    seg = 504  # triangles (= record slots) per segment
+    nseg = (105840 + seg - 1) // seg
     assert L.fr_render_depth_workspace_bytes(64, 53215, 105840, 200, 200) == \
-        64 * nseg * (512 * 16 + 64 * 2) + 2 * 64 * nseg * 512 * 16
+        64 * nseg * (seg * 16 + 64 * 2) + 2 * 64 * nseg * seg * 16
     assert L.fr_render_depth_workspace_bytes(0, 5, 5, 8, 8) == 0
     # workspace too small
     assert L.fr_render_depth_forward(one, one, one, 1, 3, 1, 4, 4, 3, 1, one, one, one, one, nul, 0, nul) == -2
