@@ -532,9 +532,11 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             const int s1 = a.rows_magic ? (int)__umulhi((uint32_t)y_max, a.rows_magic) : y_max;
             if (x_max - x_min < SMALL_W && y_max - y_min < SMALL_H && s0 == s1) {
                 const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
-                uint32_t m = 0;
+                // one flat loop over the window's pixels (not y / x nests): the compiler keeps it rolled, which holds the
+                // kernel at 56 VGPRs -- 8 waves per SIMD instead of 5
                 const int bw = x_max - x_min + 1, npx = bw * (y_max - y_min + 1);
                 int dx = 0, bit = 0, yy = y_min;
+                uint32_t m = 0;
 #pragma clang loop unroll(disable)
                 for (int k = 0; k < npx; k++) {
                     if (point_in_tri(ts, x_min + dx, yy)) m |= 1u << (bit + dx);
