@@ -399,8 +399,10 @@ __global__ __launch_bounds__(BLOCK) void render_strip_kernel(RenderArgs a) {
 }
 
 // ---- binned path, kernel 1: per-triangle setup + hit test, records counting-sorted by strip -----------------
-// record = {key.lo, key.hi, x0 | y0 << 16, mask}; mask != 0: hit bits (dy*8+dx) of an 8x4 window at (x0,y0) that lies
-// inside one strip; mask == 0: "big" record, the resolver rasterises triangle ~key.lo itself.
+// record = {key.lo, key.hi, x0 | y0 << 16, mask}; mask != 0: hit bits (dy*8+dx) of an 8x4 window at (x0,y0) -- in a
+// strip's own bucket when the window lies inside that strip, in bucket 0 when it straddles two strips (every resolver
+// reads bucket 0 and applies the rows that are its own); mask == 0 (bucket 0): "big" record, the resolver rasterises
+// triangle ~key.lo itself.
 // bucket order inside a segment: [big | strip 0 | strip 1 | ...]; segoff[0] = #big = start of strip 0,
 // segoff[s+1] = end of strip s.
 // 32-bit-offset gather: base pointer stays in SGPRs, one VALU shift per address (ids < 2^30 by construction).
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             // strip of the first / last row: y / rows through the exact 2^32 reciprocal (y, rows < 2^16)
             const int s0 = a.rows_magic ? (int)__umulhi((uint32_t)y_min, a.rows_magic) : y_min;
             const int s1 = a.rows_magic ? (int)__umulhi((uint32_t)y_max, a.rows_magic) : y_max;
-            if (x_max - x_min < SMALL_W && y_max - y_min < SMALL_H && s0 == s1) {
+            if (x_max - x_min < SMALL_W && y_max - y_min < SMALL_H) {
                 const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
                 // one flat loop over the window's pixels (not y / x nests): the compiler keeps it rolled, which holds the
                 // kernel at 56 VGPRs -- 8 waves per SIMD instead of 5
@@ -544,7 +546,9 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
                 }
                 rec.w = m;
                 emit = (m != 0);
-                bucket = 1 + s0;
+                // a window that straddles two strips goes to the shared bucket 0 WITH its mask: both strips' resolvers apply
+                // the rows that are theirs, without touching the triangle again
+                bucket = (s0 == s1) ? 1 + s0 : 0;
             } else {
                 rec.w = 0;
                 emit = true;
@@ -750,6 +754,35 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                     if (pref[k + step] <= j) k += step;
                 const uint32_t slot = (uint32_t)k * SEG + (j - pref[k]);
                 const uint4 r = Rbase[slot];
+                if (r.w) {  // straddling window: same as a small record, restricted to this strip's rows
+                    const unsigned long long key = ((unsigned long long)r.y << 32) | r.x;
+                    const int x0 = (int)(r.z & 0xFFFFu), y0 = (int)(r.z >> 16);
+                    uint32_t m = r.w, won = 0;
+                    while (m) {
+                        const int bit = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        const int y = y0 + (bit >> 3);
+                        if (y < r0 || y >= r1) continue;
+                        unsigned long long* kp = keys + (size_t)(y - r0) * W + x0 + (bit & 7);
+                        if (pass == 0)
+                            atomicMax(kp, key);
+                        else if (*kp == key)
+                            won |= 1u << bit;
+                    }
+                    if (won) {
+                        float4 nv = Nbase[slot];
+                        if (FUSED) nv = post_normal(nv);
+                        while (won) {
+                            const int bit = __ffs((int)won) - 1;
+                            won &= won - 1;
+                            float* np = nplane + NSTRIDE * ((size_t)(y0 + (bit >> 3) - r0) * W + x0 + (bit & 7));
+                            np[0] = nv.x;
+                            np[1] = nv.y;
+                            np[2] = nv.z;
+                        }
+                    }
+                    continue;
+                }
                 const int t = (int)(0xFFFFFFFFu - r.x);
                 if (pass == 0)
                     raster_triangle_into_strip<false>(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, W, r0, r1, keys);
