@@ -62,7 +62,7 @@ struct RenderArgs {
 constexpr int SEG = 504;         // triangles (and record capacity) per segment: 504 * 40 B of queue + counters <= 20 KiB,
                                  // so eight emit workgroups share a CU's 160 KiB of LDS (8 waves per SIMD)
 constexpr int OFF_STRIDE = 64;   // u16 offsets per segment (strips + 1 <= 64)
-constexpr int MAX_STRIPS = OFF_STRIDE - 1;
+constexpr int MAX_STRIPS = OFF_STRIDE / 2;  // buckets: 0 = big, 1+2s = strip s, 2+2s = windows straddling strips s / s+1
 constexpr int SMALL_W = 8, SMALL_H = 4;  // hit-mask window: bit = dy*8 + dx
 
 // XCD-aware block remap (bijective for any grid): blocks that share blockIdx%8 share an XCD/L2, so give each
@@ -400,11 +400,10 @@ __global__ __launch_bounds__(BLOCK) void render_strip_kernel(RenderArgs a) {
 
 // ---- binned path, kernel 1: per-triangle setup + hit test, records counting-sorted by strip -----------------
 // record = {key.lo, key.hi, x0 | y0 << 16, mask}; mask != 0: hit bits (dy*8+dx) of an 8x4 window at (x0,y0) -- in a
-// strip's own bucket when the window lies inside that strip, in bucket 0 when it straddles two strips (every resolver
-// reads bucket 0 and applies the rows that are its own); mask == 0 (bucket 0): "big" record, the resolver rasterises
-// triangle ~key.lo itself.
-// bucket order inside a segment: [big | strip 0 | strip 1 | ...]; segoff[0] = #big = start of strip 0,
-// segoff[s+1] = end of strip s.
+// strip's own bucket when the window lies inside that strip, in the boundary bucket between two strips when it straddles
+// them; mask == 0 (bucket 0): "big" record, the resolver rasterises triangle ~key.lo itself.
+// bucket order inside a segment: [big | strip 0 | boundary 0/1 | strip 1 | boundary 1/2 | ...], so what strip s needs --
+// boundary s-1/s, strip s, boundary s/s+1 -- is one contiguous range; segoff[k] = end of bucket k.
 // 32-bit-offset gather: base pointer stays in SGPRs, one VALU shift per address (ids < 2^30 by construction).
 __device__ __forceinline__ float ld_off(const float* __restrict__ base, uint32_t idx) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)(idx << 2));
@@ -438,7 +437,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     const int b = lid / a.nseg;
     const int seg = lid - b * a.nseg;
     const int S = a.strips;
-    if (tid <= S) cnt[tid] = 0;
+    if (tid < 2 * S) cnt[tid] = 0;
     if (tid == 0) qn = 0;
     __syncthreads();
 
@@ -546,9 +545,9 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
                 }
                 rec.w = m;
                 emit = (m != 0);
-                // a window that straddles two strips goes to the shared bucket 0 WITH its mask: both strips' resolvers apply
-                // the rows that are theirs, without touching the triangle again
-                bucket = (s0 == s1) ? 1 + s0 : 0;
+                // a window that straddles strips s0 / s0+1 goes to the bucket between the two strips' own: a strip's resolver
+                // reads [boundary above | own | boundary below] as one contiguous range and applies the rows that are its own
+                bucket = (s0 == s1) ? 1 + 2 * s0 : 2 + 2 * s0;
             } else {
                 rec.w = 0;
                 emit = true;
@@ -589,11 +588,11 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
     if (tid == 0) {
         uint32_t run = 0;
-        for (int k = 0; k <= S; k++) {
+        for (int k = 0; k < 2 * S; k++) {
             const uint32_t c = cnt[k];
             cnt[k] = run;  // start of bucket k
             run += c;
-            off[k] = (uint16_t)run;  // off[0] = #big, off[s+1] = end of strip s
+            off[k] = (uint16_t)run;  // end of bucket k (off[0] = #big)
         }
     }
     __syncthreads();
@@ -634,6 +633,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     __syncthreads();
     total = tot;
     return base + inc - v;
+}
+
+// bits of the 8x4 window mask (bit = dy*8 + dx) whose row dy is < n
+__device__ __forceinline__ uint32_t window_rows_below(int n) {
+    return n >= SMALL_H ? 0xFFFFFFFFu : (n <= 0 ? 0u : (1u << (8 * n)) - 1u);
 }
 
 constexpr size_t resolve_scratch_bytes(int block) { return (size_t)(block + 1) * 4 + (size_t)block * 2 + 64 * 4 + 16; }
@@ -678,8 +682,8 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
             if (seg < a.nseg) {
                 const uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
                 nbig = off[0];
-                lo = off[s];
-                hi = off[s + 1];
+                lo = off[s > 0 ? 2 * s - 1 : 0];                  // start of bucket 2s (s = 0: of bucket 1, past the big ones)
+                hi = off[min(2 * s + 2, 2 * a.strips - 1)];     // end of the boundary bucket below (last strip: of its own)
             }
             const uint4* Rbase = a.recs + ((size_t)b * a.nseg + c0) * SEG;
             const float4* Nbase = a.recn + ((size_t)b * a.nseg + c0) * SEG;
@@ -711,13 +715,15 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                 for (int u = 0; u < RU; u++) {
                     const unsigned long long key = ((unsigned long long)r[u].y << 32) | r[u].x;
                     const int x0 = (int)(r[u].z & 0xFFFFu), y0 = (int)(r[u].z >> 16);
-                    const size_t p0 = (size_t)(y0 - r0) * W + x0;
+                    const int p0 = (y0 - r0) * W + x0;  // may be negative for a window that starts in the strip above
                     uint32_t m = r[u].w;  // 0 for the slots past the end
+                    // rows of the 8x4 window that belong to this strip (all four unless the window straddles a boundary)
+                    m &= window_rows_below(r1 - y0) & ~window_rows_below(r0 - y0);
                     if (pass == 0) {
                         while (m) {
                             const int bit = __ffs((int)m) - 1;
                             m &= m - 1;
-                            atomicMax(keys + p0 + (bit >> 3) * W + (bit & 7), key);
+                            atomicMax(keys + (p0 + (bit >> 3) * W + (bit & 7)), key);
                         }
                     } else {
                         uint32_t won = 0;
@@ -732,7 +738,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                             while (won) {
                                 const int bit = __ffs((int)won) - 1;
                                 won &= won - 1;
-                                float* np = nplane + NSTRIDE * (p0 + (bit >> 3) * W + (bit & 7));
+                                float* np = nplane + NSTRIDE * (ptrdiff_t)(p0 + (bit >> 3) * W + (bit & 7));
                                 np[0] = nv.x;
                                 np[1] = nv.y;
                                 np[2] = nv.z;
@@ -742,7 +748,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                 }
             }
             __syncthreads();
-            // ---- the face's big / strip-straddling records (bucket 0 of every segment) ----
+            // ---- the face's big records (bucket 0 of every segment; none on a mesh of sub-pixel triangles) ----
             ex = block_exclusive_scan<BLOCK>(nbig, wtot, total);
             pref[tid] = ex;
             if (tid == 0) pref[BLOCK] = total;
@@ -754,35 +760,6 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                     if (pref[k + step] <= j) k += step;
                 const uint32_t slot = (uint32_t)k * SEG + (j - pref[k]);
                 const uint4 r = Rbase[slot];
-                if (r.w) {  // straddling window: same as a small record, restricted to this strip's rows
-                    const unsigned long long key = ((unsigned long long)r.y << 32) | r.x;
-                    const int x0 = (int)(r.z & 0xFFFFu), y0 = (int)(r.z >> 16);
-                    uint32_t m = r.w, won = 0;
-                    while (m) {
-                        const int bit = __ffs((int)m) - 1;
-                        m &= m - 1;
-                        const int y = y0 + (bit >> 3);
-                        if (y < r0 || y >= r1) continue;
-                        unsigned long long* kp = keys + (size_t)(y - r0) * W + x0 + (bit & 7);
-                        if (pass == 0)
-                            atomicMax(kp, key);
-                        else if (*kp == key)
-                            won |= 1u << bit;
-                    }
-                    if (won) {
-                        float4 nv = Nbase[slot];
-                        if (FUSED) nv = post_normal(nv);
-                        while (won) {
-                            const int bit = __ffs((int)won) - 1;
-                            won &= won - 1;
-                            float* np = nplane + NSTRIDE * ((size_t)(y0 + (bit >> 3) - r0) * W + x0 + (bit & 7));
-                            np[0] = nv.x;
-                            np[1] = nv.y;
-                            np[2] = nv.z;
-                        }
-                    }
-                    continue;
-                }
                 const int t = (int)(0xFFFFFFFFu - r.x);
                 if (pass == 0)
                     raster_triangle_into_strip<false>(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, W, r0, r1, keys);
@@ -848,6 +825,7 @@ RenderGeom render_geom(int B, int ntri, int H, int W) {
     int rows_max = row_bytes ? (int)((kLdsMax - fr::resolve_scratch_bytes(1024)) / row_bytes) : H;
     if (rows_max < 1) rows_max = 0;  // a row does not fit: unsupported
     int want_strips = B > 0 ? (512 + B - 1) / B : 1;
+    if (want_strips > fr::MAX_STRIPS) want_strips = fr::MAX_STRIPS;  // two buckets per strip must fit the offset table
     int rows = H > 0 ? (H + want_strips - 1) / want_strips : 1;
     if (rows < fr::SMALL_H) rows = fr::SMALL_H;
     int ov = env_int("FR_RENDER_ROWS", 0);  // tuning override
