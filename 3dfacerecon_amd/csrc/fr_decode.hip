@@ -406,10 +406,9 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
 
 template <int R>
 __device__ __forceinline__ void ring_wait(f32x4& slot) {
-    static_assert(R == 6 || R == 8 || R == 12, "ring size");
+    static_assert(R == 6 || R == 8, "ring size");  // (12 slots were measured too: slower, and they spill)
     if constexpr (R == 6) asm volatile("s_waitcnt vmcnt(5)" : "+v"(slot));
-    else if constexpr (R == 8) asm volatile("s_waitcnt vmcnt(7)" : "+v"(slot));
-    else asm volatile("s_waitcnt vmcnt(11)" : "+v"(slot));
+    else asm volatile("s_waitcnt vmcnt(7)" : "+v"(slot));
 }
 
 template <int GS, int GE, int R, int NBW, int DEC_WAVES>
@@ -612,12 +611,9 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
         a.halves = (nbt + nbw - 1) / nbw;
         // the model's own basis shape (199 + 29 coefficients = 13 + 2 groups) takes the fully unrolled ring schedule
         static const bool loop_env = getenv("FR_DECODE_IMPL") && !strcmp(getenv("FR_DECODE_IMPL"), "loop");
-        static const int ring_env = getenv("FR_DECODE_RING") ? atoi(getenv("FR_DECODE_RING")) : 8;
         const bool ring = !loop_env && groups_of(n_shape) == 13 && groups_of(n_exp) == 2 && nbw <= 2;
         int rc;
         if (ring && nbw == 1) rc = launch_decode_ring<13, 2, 8, 1, 16>(a, lds, cus, tiles, stream);
-        else if (ring && ring_env == 6) rc = launch_decode_ring<13, 2, 6, 2, 16>(a, lds, cus, tiles, stream);
-        else if (ring && ring_env == 12) rc = launch_decode_ring<13, 2, 12, 2, 16>(a, lds, cus, tiles, stream);
         else if (ring) rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);
         else
             rc = nbw == 1   ? launch_decode_nbw<1, 16>(a, lds, cus, tiles, stream)

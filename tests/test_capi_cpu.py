@@ -141,3 +141,22 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         d.shard_range(4, 2, 2)
+
+
+def test_ring_decode_kernel_keeps_its_stream_in_registers():
+    """decode_ring_kernel issues its A-fragment requests through inline asm and counts them by hand (s_waitcnt vmcnt(R-1)):
+    that accounting is only valid if the compiler neither spills an in-flight ring slot nor adds scratch traffic, which
+    shares the vmcnt counter.  The compiler's own resource report must show no scratch for every instantiation."""
+    import subprocess
+    h = pkg("_lib")
+    src = os.path.join(h._CSRC, "fr_decode.hip")
+    cmd = [h._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", "--cuda-device-only",
+           "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, src]
+    out = subprocess.run(cmd, cwd=h._CSRC, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", out.stderr)[1:]
+    ring = [b for b in blocks if b.startswith("_ZN2fr18decode_ring_kernel")]
+    assert len(ring) >= 2
+    for b in ring:
+        assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", b), b[:400]
+        assert re.search(r"VGPRs Spill: 0\b", b), b[:400]

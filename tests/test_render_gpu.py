@@ -67,6 +67,77 @@ def test_random_scenes(oracle, B, nver, ntri, H, W, scale):
     assert_render_equal(render_gpu(ver, tri, tex, H, W), oracle.render_depth(ver, tri, tex, H, W), "random")
 
 
+def _subpixel_mesh(rs, B, H, W, nu, nv, jitter):
+    """A jittered nu x nv vertex grid stretched over the image (plus a margin): every cell is ~1 px, so the triangles are
+    the sub-pixel kind the 3DMM mesh projects to, and every strip boundary is crossed by a row of them."""
+    gx, gy = np.meshgrid(np.linspace(-2.0, W + 1.0, nv), np.linspace(-2.0, H + 1.0, nu))
+    nver = nu * nv
+    ver = np.empty((B, 3, nver), np.float32)
+    for b in range(B):
+        ver[b, 0] = (gx + rs.uniform(-jitter, jitter, gx.shape)).reshape(-1)
+        ver[b, 1] = (gy + rs.uniform(-jitter, jitter, gy.shape)).reshape(-1)
+        ver[b, 2] = rs.uniform(-5, 5, nver)
+    iu, iv = np.meshgrid(np.arange(nu - 1), np.arange(nv - 1), indexing="ij")
+    v00 = (iu * nv + iv).reshape(-1)
+    tri = np.concatenate([np.stack([v00, v00 + nv, v00 + 1]), np.stack([v00 + 1, v00 + nv, v00 + nv + 1])], 1)
+    tri = tri[:, rs.permutation(tri.shape[1])].astype(np.float32)   # no helpful ordering
+    tex = rs.uniform(0, 1, (1, 3, nver)).astype(np.float32)
+    return ver, tri, tex
+
+
+@pytest.mark.parametrize("B,H,W,nu,nv", [
+    (2, 60, 64, 90, 96),      # few faces: many thin strips (the strip count is capped by the offset table)
+    (64, 40, 40, 56, 56),     # the bench's batch size: ~512 bins
+    (9, 100, 37, 140, 50),    # odd sizes, ragged last strip
+])
+def test_subpixel_mesh_across_strip_boundaries(oracle, B, H, W, nu, nv):
+    rs = np.random.RandomState(B * 7 + H)
+    ver, tri, tex = _subpixel_mesh(rs, B, H, W, nu, nv, 0.45)
+    want = oracle.render_depth(ver, tri, tex, H, W)
+    assert (want[3] >= 0).mean() > 0.5     # the mesh really covers the image
+    assert_render_equal(render_gpu(ver, tri, tex, H, W), want, "subpixel")
+
+
+def test_pixel_centres_within_ulps_of_edges(oracle):
+    """Triangles whose edges pass exactly through pixel centres, then with one vertex moved by -2..2 float ulps: the hit
+    test must follow the reference's fp64 arithmetic bit for bit (u, v, u+v sit at 0 / 1 up to rounding)."""
+    rs = np.random.RandomState(77)
+    H = W = 48
+    vs, ts = [], []
+    for k in range(600):
+        # an integer-coordinate pixel centre c, and an edge through it: a = c - d*s, b = c + d*t with a random direction
+        c = rs.randint(4, 44, 2).astype(np.float64)
+        d = rs.uniform(-1, 1, 2)
+        a = c - d * rs.uniform(0.2, 3.0)
+        b = c + d * rs.uniform(0.2, 3.0)
+        third = c + rs.uniform(-3, 3, 2)
+        pts = np.stack([a, b, third]).astype(np.float32)
+        pts = pts[rs.permutation(3)]
+        j, ax = rs.randint(0, 3), rs.randint(0, 2)
+        steps = int(rs.randint(-2, 3))
+        for _ in range(abs(steps)):
+            pts[j, ax] = np.nextafter(pts[j, ax], np.float32(np.inf if steps > 0 else -np.inf))
+        n0 = len(vs)
+        for q in pts:
+            vs.append([q[0], q[1], rs.uniform(-3, 3)])
+        ts.append([n0, n0 + 1, n0 + 2])
+    # exact cases too: vertices on half-integer / integer lattices (edges through many centres, zero-area slivers)
+    for k in range(300):
+        q = rs.randint(2, 2 * 44, (3, 2)).astype(np.float32) / 2.0
+        n0 = len(vs)
+        for r in q:
+            vs.append([r[0], r[1], rs.uniform(-3, 3)])
+        ts.append([n0, n0 + 1, n0 + 2])
+    ver = np.asarray(vs, np.float32).T[None].copy()
+    tri = np.asarray(ts, np.float32).T.copy()
+    tex = rs.uniform(0, 1, (1, 3, ver.shape[2])).astype(np.float32)
+    assert_render_equal(render_gpu(ver, tri, tex, H, W), oracle.render_depth(ver, tri, tex, H, W), "near-edge")
+    # one triangle at a time (no occlusion hiding a wrong hit): coverage of each must match
+    for k in range(0, 900, 9):
+        t1 = tri[:, k:k + 1]
+        assert_render_equal(render_gpu(ver, t1, tex, H, W), oracle.render_depth(ver, t1, tex, H, W), "near-edge single %d" % k)
+
+
 def test_shared_texture(oracle):
     rs = np.random.RandomState(3)
     ver, tri, tex = _random_scene(rs, 3, 100, 200, 20, 20, 3.0)
