@@ -205,36 +205,62 @@ __global__ __launch_bounds__(BW_WAVES * 64) void bwd_gemm_kernel(BwdArgs a) {
 }
 
 // ---- fixed-order reduction of the partials ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bwd_reduce_kernel(BwdArgs a) {
+// One 1024-thread workgroup per 64 consecutive outputs (output i = what*64 + batch: what 0..3 = d t3d / d f, 4.. = the
+// padded coefficients).  Wave w sums its contiguous 1/16 of the partials with eight independent loads in flight per
+// lane (the slabs are contiguous in i, so every load is a 256-byte row); the 16 wave sums meet in LDS and are added in
+// wave order.  The association is fixed by (gemm_blocks, pre_blocks) alone, so the result is bit-reproducible.
+constexpr int RED_WAVES = 16;
+__global__ __launch_bounds__(RED_WAVES * 64) void bwd_reduce_kernel(BwdArgs a) {
+    __shared__ float part[RED_WAVES][64];
     const int nd = FR_N_POSE + a.ns + a.ne;
     const int GSB = (a.ns + 15) / 16;
-    const int total = 64 * (4 + BW_MAXCOEF);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int b = i & 63, what = i >> 6;
-        if (b >= a.nbatch) continue;
-        float* gp = a.grad_params + (size_t)(a.b0 + b) * nd;
-        if (what < 4) {
-            float s = 0.f;
-            for (int k = 0; k < a.pre_blocks; k++) s += a.pose_part[((size_t)k * 64 + b) * 4 + what];
-            if (what < 3) {
-                gp[3 + what] = s;
-                gp[what] = 0.0f;  // angles: no gradient through tf.py_func (network.py:150)
-            } else {
-                gp[6] = s;
-            }
-        } else {
-            const int coef = what - 4;
-            const int cb = coef >> 4, cc = coef & 15;
-            int dst = -1;
-            if (cb < GSB) {
-                if (cb * 16 + cc < a.ns) dst = FR_N_POSE + cb * 16 + cc;
-            } else if ((cb - GSB) * 16 + cc < a.ne) {
-                dst = FR_N_POSE + a.ns + (cb - GSB) * 16 + cc;
-            }
-            if (dst < 0) continue;
-            float s = 0.f;
-            for (int k = 0; k < a.gemm_blocks; k++) s += a.slab[((size_t)k * BW_MAXCOEF + coef) * 64 + b];
-            gp[dst] = s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int what = blockIdx.x, b = lane;  // i = what * 64 + b
+    const float* src;
+    size_t kstride;
+    int nk;
+    if (what < 4) {
+        src = a.pose_part + (size_t)b * 4 + what;
+        kstride = 64 * 4;
+        nk = a.pre_blocks;
+    } else {
+        src = a.slab + (size_t)(what - 4) * 64 + b;
+        kstride = (size_t)BW_MAXCOEF * 64;
+        nk = a.gemm_blocks;
+    }
+    const int per = (nk + RED_WAVES - 1) / RED_WAVES;
+    const int k0 = wave * per, k1 = min(nk, k0 + per);
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) s[u] = 0.f;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[(size_t)(k + u) * kstride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s[u] += v[u];
+    }
+    for (; k < k1; k++) s[0] += src[(size_t)k * kstride];
+    part[wave][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (wave != 0 || b >= a.nbatch) return;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < RED_WAVES; w++) tot += part[w][lane];
+    float* gp = a.grad_params + (size_t)(a.b0 + b) * nd;
+    if (what < 3) {
+        gp[3 + what] = tot;
+        gp[what] = 0.0f;  // angles: no gradient through tf.py_func (network.py:150)
+    } else if (what == 3) {
+        gp[6] = tot;
+    } else {
+        const int coef = what - 4;
+        const int cb = coef >> 4, cc = coef & 15;
+        if (cb < GSB) {
+            if (cb * 16 + cc < a.ns) gp[FR_N_POSE + cb * 16 + cc] = tot;
+        } else if ((cb - GSB) * 16 + cc < a.ne) {
+            gp[FR_N_POSE + a.ns + (cb - GSB) * 16 + cc] = tot;
         }
     }
 }
@@ -291,7 +317,7 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
         a.nbatch = min(B - b0, 64);
         hipLaunchKernelGGL(bwd_prepass_kernel, dim3(g.pre_blocks), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(bwd_gemm_kernel, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
-        hipLaunchKernelGGL(bwd_reduce_kernel, dim3(64), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(bwd_reduce_kernel, dim3(4 + BW_MAXCOEF), dim3(RED_WAVES * 64), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
