@@ -32,12 +32,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--im-size", type=int, default=200)
     args = ap.parse_args()
+    S = args.im_size
     synth, netm, pipe = pkg("utils.synth"), pkg("nets.network"), pkg("pipeline")
     A = synth.make_assets()
-    net = netm.FaceRecNet(mesh_data=A, batch_size=args.batch, im_size=200, device="cuda:0")
-    plan = pipe.DecodeRenderPlan(net, args.batch, 200, 200)
-    plan.params.copy_(torch.as_tensor(synth.sample_params_batch(args.batch, beta=0.7), device="cuda:0"))
+    net = netm.FaceRecNet(mesh_data=A, batch_size=args.batch, im_size=S, device="cuda:0")
+    plan = pipe.DecodeRenderPlan(net, args.batch, S, S)
+    plan.params.copy_(torch.as_tensor(synth.sample_params_batch(args.batch, im_size=S, beta=0.7), device="cuda:0"))
     plan.step()
     print("decode only   %.1f us" % timeit(plan.decode, args.iters))
     print("render only   %.1f us" % timeit(plan.render, args.iters))
@@ -48,7 +50,7 @@ def main():
     ops = pkg("rendering_layer.ops")
     P = plan.params.clone().requires_grad_(True)
     V = net.vertices_transform(P)
-    outs = ops.render_depth(V, net.tri, net.vertex_code, torch.zeros((args.batch, 200, 200, 3), device="cuda:0"))
+    outs = ops.render_depth(V, net.tri, net.vertex_code, torch.zeros((args.batch, S, S, 3), device="cuda:0"))
     g = torch.ones_like(outs[0])
 
     def bwd():
