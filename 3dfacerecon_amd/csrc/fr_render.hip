@@ -640,7 +640,7 @@ __device__ __forceinline__ uint32_t window_rows_below(int n) {
     return n >= SMALL_H ? 0xFFFFFFFFu : (n <= 0 ? 0u : (1u << (8 * n)) - 1u);
 }
 
-constexpr size_t resolve_scratch_bytes(int block) { return (size_t)(block + 1) * 4 + (size_t)block * 2 + 64 * 4 + 16; }
+constexpr size_t resolve_scratch_bytes(int block) { return 2 * (size_t)(block + 1) * 4 + (size_t)block * 2 + 64 * 4 + 16; }
 
 // The bin's records are spread over the face's segments (a few per segment).  Walking segments one after the other
 // would serialise ~4 dependent memory round trips per segment; instead the per-segment counts are prefix-summed in
@@ -657,8 +657,9 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     const int W = a.W;
     const int npix = (r1 - r0) * W;
     // scratch behind the keys of a full strip (the launcher sizes the dynamic LDS for it)
-    uint32_t* pref = reinterpret_cast<uint32_t*>(keys + (size_t)a.rows * W);  // [BLOCK+1]
-    uint16_t* lo16 = reinterpret_cast<uint16_t*>(pref + BLOCK + 1);            // [BLOCK]
+    uint32_t* pref = reinterpret_cast<uint32_t*>(keys + (size_t)a.rows * W);  // [BLOCK+1] small-record list offsets
+    uint32_t* prefb = pref + BLOCK + 1;                                         // [BLOCK+1] big-record list offsets
+    uint16_t* lo16 = reinterpret_cast<uint16_t*>(prefb + BLOCK + 1);           // [BLOCK]
     uint32_t* wtot = reinterpret_cast<uint32_t*>(lo16 + BLOCK);                 // [64] (BLOCK even: 4-byte aligned)
     const unsigned long long KBG = bg_key();
     for (int i = tid; i < npix; i += BLOCK) keys[i] = KBG;
@@ -675,25 +676,34 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     // pass 0: z-resolve -- every hit becomes one ds_max_u64.  pass 1: the winners are known; each record looks its hit
     // pixels up again and, where its key won, stores its normal (kept in the record's companion slot) to the normal
     // plane.  The second read of the records is an L1/L2 hit.
+    const bool one_chunk = a.nseg <= BLOCK;  // the usual case: the offsets and both scans are done once, not per pass
     for (int pass = 0; pass < 2; pass++) {
         for (int c0 = 0; c0 < a.nseg; c0 += BLOCK) {
-            const int seg = c0 + tid;
-            uint32_t nbig = 0, lo = 0, hi = 0;
-            if (seg < a.nseg) {
-                const uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
-                nbig = off[0];
-                lo = off[s > 0 ? 2 * s - 1 : 0];                  // start of bucket 2s (s = 0: of bucket 1, past the big ones)
-                hi = off[min(2 * s + 2, 2 * a.strips - 1)];     // end of the boundary bucket below (last strip: of its own)
-            }
             const uint4* Rbase = a.recs + ((size_t)b * a.nseg + c0) * SEG;
             const float4* Nbase = a.recn + ((size_t)b * a.nseg + c0) * SEG;
-            // ---- this strip's small records ----
-            uint32_t total;
-            uint32_t ex = block_exclusive_scan<BLOCK>(hi - lo, wtot, total);
-            pref[tid] = ex;
-            lo16[tid] = (uint16_t)lo;
-            if (tid == 0) pref[BLOCK] = total;
-            __syncthreads();  // also orders the key initialisation before the first atomics
+            if (pass == 0 || !one_chunk) {
+                const int seg = c0 + tid;
+                uint32_t nbig = 0, lo = 0, hi = 0;
+                if (seg < a.nseg) {
+                    const uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
+                    nbig = off[0];
+                    lo = off[s > 0 ? 2 * s - 1 : 0];               // start of bucket 2s (s = 0: of bucket 1, past the big ones)
+                    hi = off[min(2 * s + 2, 2 * a.strips - 1)];  // end of the boundary bucket below (last strip: of its own)
+                }
+                uint32_t tot_s, tot_b;
+                const uint32_t ex_s = block_exclusive_scan<BLOCK>(hi - lo, wtot, tot_s);
+                const uint32_t ex_b = block_exclusive_scan<BLOCK>(nbig, wtot, tot_b);
+                pref[tid] = ex_s;
+                prefb[tid] = ex_b;
+                lo16[tid] = (uint16_t)lo;
+                if (tid == 0) {
+                    pref[BLOCK] = tot_s;
+                    prefb[BLOCK] = tot_b;
+                }
+                __syncthreads();  // also orders the key initialisation before the first atomics
+            }
+            // ---- this strip's small records (own bucket + the two boundary buckets) ----
+            const uint32_t total = pref[BLOCK];
             for (uint32_t j0 = tid; j0 < total; j0 += BLOCK * RU) {
                 uint4 r[RU];
                 uint32_t slot[RU];
@@ -747,18 +757,14 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                     }
                 }
             }
-            __syncthreads();
             // ---- the face's big records (bucket 0 of every segment; none on a mesh of sub-pixel triangles) ----
-            ex = block_exclusive_scan<BLOCK>(nbig, wtot, total);
-            pref[tid] = ex;
-            if (tid == 0) pref[BLOCK] = total;
-            __syncthreads();
-            for (uint32_t j = tid; j < total; j += BLOCK) {
+            const uint32_t totalb = prefb[BLOCK];
+            for (uint32_t j = tid; j < totalb; j += BLOCK) {
                 int k = 0;
 #pragma unroll
                 for (int step = BLOCK >> 1; step > 0; step >>= 1)
-                    if (pref[k + step] <= j) k += step;
-                const uint32_t slot = (uint32_t)k * SEG + (j - pref[k]);
+                    if (prefb[k + step] <= j) k += step;
+                const uint32_t slot = (uint32_t)k * SEG + (j - prefb[k]);
                 const uint4 r = Rbase[slot];
                 const int t = (int)(0xFFFFFFFFu - r.x);
                 if (pass == 0)

@@ -138,6 +138,14 @@ def test_pixel_centres_within_ulps_of_edges(oracle):
         assert_render_equal(render_gpu(ver, t1, tex, H, W), oracle.render_depth(ver, t1, tex, H, W), "near-edge single %d" % k)
 
 
+def test_more_segments_than_resolver_threads(oracle):
+    """> 512 * 504 triangles: the resolver walks the segment list in more than one chunk."""
+    rs = np.random.RandomState(11)
+    B, nver, ntri, H, W = 2, 5000, 300000, 48, 64
+    ver, tri, tex = _random_scene(rs, B, nver, ntri, H, W, 1.5)
+    assert_render_equal(render_gpu(ver, tri, tex, H, W), oracle.render_depth(ver, tri, tex, H, W), "many segments")
+
+
 def test_shared_texture(oracle):
     rs = np.random.RandomState(3)
     ver, tri, tex = _random_scene(rs, 3, 100, 200, 20, 20, 3.0)
