@@ -586,13 +586,17 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     __syncthreads();
     // ---------------- phase C: bucket offsets, records out ----------------
     uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int k = 0; k < 2 * S; k++) {
-            const uint32_t c = cnt[k];
-            cnt[k] = run;  // start of bucket k
-            run += c;
-            off[k] = (uint16_t)run;  // end of bucket k (off[0] = #big)
+    if (tid < 64) {  // one wave scans the (at most 64) bucket counts
+        const uint32_t c = (tid < 2 * S) ? cnt[tid] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t n = __shfl_up(inc, d);
+            if (lane >= d) inc += n;
+        }
+        if (tid < 2 * S) {
+            cnt[tid] = inc - c;          // start of bucket k
+            off[tid] = (uint16_t)inc;    // end of bucket k (off[0] = #big)
         }
     }
     __syncthreads();
