@@ -60,6 +60,9 @@ def _random_scene(rs, B, nver, ntri, H, W, scale):
     (1, 200, 300, 7, 450, 5.0),     # wide image (448+ wide rows)
     (4, 64, 40, 100, 3, 2.0),       # narrow image
     (70, 120, 200, 24, 28, 2.5),    # more faces than one pass of bins per CU
+    (2, 50, 100, 1, 1, 1.0),        # one-pixel image
+    (2, 50, 100, 2, 3, 1.0),        # fewer rows than the 8x4 hit-mask window
+    (1, 60, 150, 3, 64, 2.0),
 ])
 def test_random_scenes(oracle, B, nver, ntri, H, W, scale):
     rs = np.random.RandomState(B * 1000 + ntri)
