@@ -834,7 +834,7 @@ RenderGeom render_geom(int B, int ntri, int H, int W) {
     const size_t row_bytes = (size_t)W * sizeof(unsigned long long);
     int rows_max = row_bytes ? (int)((kLdsMax - fr::resolve_scratch_bytes(1024)) / row_bytes) : H;
     if (rows_max < 1) rows_max = 0;  // a row does not fit: unsupported
-    int want_strips = B > 0 ? (512 + B - 1) / B : 1;
+    int want_strips = B > 0 ? (1280 + B - 1) / B : 1;  // ~5 resolver workgroups of 256 threads per CU (10-row strips at B = 64)
     if (want_strips > fr::MAX_STRIPS) want_strips = fr::MAX_STRIPS;  // two buckets per strip must fit the offset table
     int rows = H > 0 ? (H + want_strips - 1) / want_strips : 1;
     if (rows < fr::SMALL_H) rows = fr::SMALL_H;
@@ -946,14 +946,15 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     if (phases & 1)
         hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
     if (!(phases & 2)) return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
-    const int rblk = env_int("FR_RESOLVE_BLOCK", 512);
+    // 256-thread resolvers when several of them fit a CU's LDS side by side, 512 threads for wide strips
+    const int rblk = env_int("FR_RESOLVE_BLOCK", g.lds <= 32 * 1024 ? 256 : 512);
     int rc;
-    if (rblk == 256)
-        rc = fused ? launch_resolve<256, true>(a, nbins, g.lds, stream) : launch_resolve<256, false>(a, nbins, g.lds, stream);
-    else if (rblk == 1024)
+    if (rblk == 1024)
         rc = fused ? launch_resolve<1024, true>(a, nbins, g.lds, stream) : launch_resolve<1024, false>(a, nbins, g.lds, stream);
-    else
+    else if (rblk == 512)
         rc = fused ? launch_resolve<512, true>(a, nbins, g.lds, stream) : launch_resolve<512, false>(a, nbins, g.lds, stream);
+    else
+        rc = fused ? launch_resolve<256, true>(a, nbins, g.lds, stream) : launch_resolve<256, false>(a, nbins, g.lds, stream);
     if (rc != FR_OK) return rc;
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
