@@ -473,6 +473,9 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_ring_kernel(DecodeArgs 
 #pragma unroll
         for (int nb = 0; nb < NBW; nb++) c[cc][nb] = sv[cc][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // live k-steps (of 4) in the last shape / expression group
+    const int ks_s = GS > 0 ? (a.ns - KGROUP * (GS - 1) + 3) / 4 : 4;
+    const int ks_e = GE > 0 ? (a.ne - KGROUP * (GE - 1) + 3) / 4 : 4;
     for (int ct = tile0; ct < tiles; ct += tstride) {
         int nt = ct + tstride;  // tile whose fragments are requested once this item's run out
         if (nt >= tiles) nt = tile0;  // past the end: harmless re-request of a valid address, never consumed
@@ -500,10 +503,14 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_ring_kernel(DecodeArgs 
                 if constexpr (FR_PROBE_DECODE & 1) {
                     c[cc][0] += af;
                 } else {
+                    // k-steps that hold only padding (199 = 12*16 + 7 leaves two of the last shape group's four) are
+                    // skipped: their products are +0 (zero basis x zero parameter) and the chains, started from +0, are
+                    // never -0, so adding them changes nothing -- and the oracle's chains do not contain them
+                    const int live = (g == GS - 1) ? ks_s : (g == G - 1) ? ks_e : 4;
                     mfma_step<NBW>(af.x, bq[0], c[cc]);
-                    mfma_step<NBW>(af.y, bq[1], c[cc]);
-                    mfma_step<NBW>(af.z, bq[2], c[cc]);
-                    mfma_step<NBW>(af.w, bq[3], c[cc]);
+                    if (live > 1) mfma_step<NBW>(af.y, bq[1], c[cc]);
+                    if (live > 2) mfma_step<NBW>(af.z, bq[2], c[cc]);
+                    if (live > 3) mfma_step<NBW>(af.w, bq[3], c[cc]);
                 }
             } else {  // mu fragment of coordinate cc: v = (mu + S) + E   (network.py:159)
                 const f32x4 m = ring[f % R];
