@@ -106,20 +106,25 @@ __device__ __forceinline__ void raster_triangle_into_strip(int t, const float* _
     if (!(h > bg_depth())) return;                    // NaN or <= background can never pass 'depth < h' (:295)
     const unsigned long long key = make_key(h, t);
     const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
-    for (int y = ya; y <= yb; y++) {
-        unsigned long long* row = keys + (size_t)(y - r0) * W;
-        for (int x = x_min; x <= x_max; x++) {
-            if (point_in_tri(ts, x, y)) {
-                if constexpr (!WINNER) {
-                    atomicMax(&row[x], key);
-                } else if (row[x] == key) {
-                    float* np = nplane + (size_t)nstride * ((size_t)(y - r0) * W + x);
-                    np[0] = nval.x;
-                    np[1] = nval.y;
-                    np[2] = nval.z;
-                }
+    // one flat, rolled loop over the bbox (not y / x nests): keeps this rarely taken path from setting the resolver's
+    // register budget
+    const int bw = x_max - x_min + 1;
+    const long long npx = (long long)bw * (yb - ya + 1);
+    int x = x_min, y = ya;
+#pragma clang loop unroll(disable)
+    for (long long k = 0; k < npx; k++) {
+        if (point_in_tri(ts, x, y)) {
+            unsigned long long* kp = keys + (size_t)(y - r0) * W + x;
+            if constexpr (!WINNER) {
+                atomicMax(kp, key);
+            } else if (*kp == key) {
+                float* np = nplane + (size_t)nstride * ((size_t)(y - r0) * W + x);
+                np[0] = nval.x;
+                np[1] = nval.y;
+                np[2] = nval.z;
             }
         }
+        if (++x > x_max) { x = x_min; y++; }
     }
 }
 
@@ -233,7 +238,10 @@ __device__ __forceinline__ void write_strip_fused(const RenderArgs& a, int b, in
 }
 
 // resolve + write the strip's four planes from the LDS keys (16-byte stores when the strip is 4-pixel aligned)
-template <int BLOCK>
+// BINNED: the caller is the binned path's resolver (winners' normals already stored, texture means in the table);
+// otherwise the fallback kernel, which resolves everything from the vertices.  A compile-time switch so that the
+// resolver does not carry the fallback writer's register budget.
+template <int BLOCK, bool BINNED>
 __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, int npix,
                                             const unsigned long long* keys, const float* __restrict__ vx,
                                             const float* __restrict__ vy, const float* __restrict__ vz) {
@@ -248,7 +256,7 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
     float* nrm = a.normal + pix0 * 3;
     const bool vec_ok = ((npix & 3) == 0) && ((pix0 & 3) == 0) &&
                         ((((uintptr_t)a.depth | (uintptr_t)a.tri_ind | (uintptr_t)a.tex_img | (uintptr_t)a.normal) & 15) == 0);
-    if (a.recn != nullptr && ntri > 0) {
+    if constexpr (BINNED) {
         // binned path: the normals of the covered pixels were already stored by the resolver's second pass; here
         // depth / tri_ind / texture go out for every pixel and zeros for the background pixels' normals.  One pixel per
         // lane: neighbouring lanes hold neighbouring pixels -> neighbouring triangles -> shared table lines.
@@ -288,7 +296,9 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
                 }
             }
         }
-    } else if (vec_ok) {
+        return;
+    }
+    if (vec_ok) {
         // Four consecutive pixels per lane (16-byte stores).  The winner's data sits two dependent gathers away
         // (key -> vertex ids -> positions / texture); all loads of the four pixels are issued together and
         // unconditionally (background pixels read triangle 0 with clamped ids and discard it), so a pass costs two
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) void render_strip_kernel(RenderArgs a) {
     for (int t = tid; t < a.ntri; t += BLOCK)
         raster_triangle_into_strip(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, a.W, r0, r1, keys);
     __syncthreads();
-    write_strip<BLOCK>(a, b, r0, npix, keys, vx, vy, vz);
+    write_strip<BLOCK, false>(a, b, r0, npix, keys, vx, vy, vz);
 }
 
 // ---- binned path, kernel 1: per-triangle setup + hit test, records counting-sorted by strip -----------------
@@ -783,7 +793,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     if (FUSED)
         write_strip_fused<BLOCK>(a, b, r0, npix, keys);
     else
-        write_strip<BLOCK>(a, b, r0, npix, keys, vx, vy, vz);
+        write_strip<BLOCK, true>(a, b, r0, npix, keys, vx, vy, vz);
 }
 
 // ---- backward: zeros + scatter-add of g/3 to the z row (render_depth_op.cc:345-363) -------------------------
