@@ -198,7 +198,7 @@ def main():
         roof_emit = {"bound": "hbm", "kernel": "raster_emit_kernel (fr_render_depth_forward, phase 1)",
                      "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "traffic": None, "avg_ms": emit_ms, "algorithmic_bytes_per_launch": emit_bytes}
-        roof_resolve = {"bound": "hbm", "kernel": "resolve_write_kernel<512> (fr_render_depth_forward, phase 2)",
+        roof_resolve = {"bound": "hbm", "kernel": "resolve_write_kernel<256> (fr_render_depth_forward, phase 2)",
                         "achieved": resolve_bytes / (resolve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "traffic": None, "avg_ms": resolve_ms, "algorithmic_bytes_per_launch": resolve_bytes}
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json:
