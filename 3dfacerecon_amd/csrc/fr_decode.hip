@@ -185,13 +185,14 @@ __device__ __forceinline__ TileWalk tile_walk(int slot, int slots, int b, int gr
 // LDS image of the parameters (B operand), per half hf: P[hf][k][j][NBW] floats -- lane l of k-step s reads the NBW
 // consecutive floats at (s*64 + l)*NBW, i.e. one conflict-free ds_read_b32/b64 per k-step.
 // Per-CU prologue shared by the decode kernels: the parameters go to LDS in B-fragment order, the pose to Mt = f.R | t3d.
-template <int NBW, int DEC_BLOCK>
+template <int NBW, int DEC_BLOCK, int MB = 64>
 __device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem, float* Mt, double* SC, int GS, int GE,
                                                 size_t half_floats, int tid, int nd, int nbatch) {
     // parameters -> LDS in B-fragment order: TPR threads per batch row, each walks the row with stride
     // TPR; loads are unconditional (clamped) and batched so they pipeline; padding slots and absent rows are 0.
     {
-        constexpr int TPR = DEC_BLOCK / 64;  // threads per batch row
+        static_assert(DEC_BLOCK % MB == 0 && DEC_BLOCK >= 3 * MB, "threads per batch row / sincos threads");
+        constexpr int TPR = DEC_BLOCK / MB;  // threads per batch row
         const int bb = tid / TPR, sub = tid - bb * TPR;
         const bool rowok = bb < nbatch;
         const float* prow = a.params + (size_t)(a.b0 + (rowok ? bb : 0)) * nd + FR_N_POSE;
@@ -223,8 +224,8 @@ __device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem
             }
         }
     }
-    // pose: the 192 float64 sincos evaluations are spread over 192 threads, then 64 threads assemble f*R and t
-    if (tid < 192 && !a.R_override) {
+    // pose: the 3*MB float64 sincos evaluations are spread over 3*MB threads, then MB threads assemble f*R and t
+    if (tid < 3 * MB && !a.R_override) {
         const int b = tid / 3, ang = tid - 3 * b;
         double sn = 0.0, cs = 1.0;
         if (b < nbatch) sincos((double)a.params[(size_t)(a.b0 + b) * nd + ang], &sn, &cs);
@@ -232,7 +233,7 @@ __device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem
         SC[(b * 3 + ang) * 2 + 1] = cs;
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < MB) {
         float m[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) m[i] = 0.f;
@@ -411,7 +412,7 @@ __device__ __forceinline__ void ring_wait(f32x4& slot) {
     else asm volatile("s_waitcnt vmcnt(7)" : "+v"(slot));
 }
 
-template <int GS, int GE, int R, int NBW, int DEC_WAVES>
+template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64>
 __global__ __launch_bounds__(DEC_WAVES * 64) void decode_ring_kernel(DecodeArgs a) {
     constexpr int DEC_BLOCK = DEC_WAVES * 64;
     constexpr int G = GS + GE;
@@ -420,11 +421,11 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_ring_kernel(DecodeArgs 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = G * KGROUP;
     constexpr size_t half_floats = (size_t)KP * 16 * NBW;
-    float* Mt = smem + (size_t)KP * 16 * 4;
-    double* SC = reinterpret_cast<double*>(Mt + 64 * 12);
+    float* Mt = smem + (size_t)KP * MB;              // [MB][12] after the MB / 16 column blocks' parameters
+    double* SC = reinterpret_cast<double*>(Mt + MB * 12);  // [MB][3][2] sin/cos of the pose angles
     const int tid = threadIdx.x;
     const int nd = FR_N_POSE + a.ns + a.ne;
-    const int nbatch = min(a.B - a.b0, 64);
+    const int nbatch = min(a.B - a.b0, MB);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles = tiles_of(a.N);
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_ring_kernel(DecodeArgs 
 #pragma unroll
         for (int f = 0; f < R; f++) FR_REQ(f, f, t0c)
     }
-    if constexpr (!(FR_PROBE_DECODE & 4)) decode_prologue<NBW, DEC_BLOCK>(a, smem, Mt, SC, GS, GE, half_floats, tid, nd, nbatch);
+    if constexpr (!(FR_PROBE_DECODE & 4)) decode_prologue<NBW, DEC_BLOCK, MB>(a, smem, Mt, SC, GS, GE, half_floats, tid, nd, nbatch);
     if (tile0 >= tiles) {
 #pragma unroll
         for (int f = 0; f < R; f++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[f]));
@@ -580,15 +581,15 @@ static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int cus, size_
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
-template <int GS, int GE, int R, int NBW, int WAVES>
+template <int GS, int GE, int R, int NBW, int WAVES, int MB = 64>
 static int launch_decode_ring(const fr::DecodeArgs& a, size_t lds, int cus, size_t tiles, hipStream_t stream) {
     static unsigned char lds_ok[64];
-    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES>), lds_ok) !=
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB>), lds_ok) !=
         hipSuccess)
         return FR_ERR_LAUNCH;
     const int slots = WAVES / a.halves;
     const int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
-    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
@@ -609,16 +610,28 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
     a.B = B; a.N = N; a.ns = n_shape; a.ne = n_exp;
     a.im_size = im_size;
     const int cus = device_cu_count();
-    for (int b0 = 0; b0 < B; b0 += MAXB) {
+    static const bool loop_env = getenv("FR_DECODE_IMPL") && !strcmp(getenv("FR_DECODE_IMPL"), "loop");
+    static const bool wide_off = getenv("FR_DECODE_WIDE") && !strcmp(getenv("FR_DECODE_WIDE"), "0");
+    const bool ring_shape = !loop_env && groups_of(n_shape) == 13 && groups_of(n_exp) == 2;
+    // 128 columns per pass (64-column items on 12 waves) when more than 64 remain: the basis is streamed once per 128
+    // faces instead of once per 64 (102 vs 110 us at B = 128; FR_DECODE_WIDE=0 turns it off)
+    const size_t lds_wide = G * KGROUP * 32 * sizeof(float4) + 128 * 12 * sizeof(float) + 128 * 3 * 2 * sizeof(double);
+    for (int b0 = 0; b0 < B;) {
         a.b0 = b0;
+        if (ring_shape && !wide_off && B - b0 > MAXB && lds_wide <= 160 * 1024) {
+            a.halves = 2;  // two 64-column items per tile (32-column items on 16 waves measured the same)
+            int rc = launch_decode_ring<13, 2, 8, 4, 12, 128>(a, lds_wide, cus, tiles, stream);
+            if (rc != FR_OK) return rc;
+            b0 += 2 * MAXB;
+            continue;
+        }
         const int nbt = (min(B - b0, MAXB) + 15) / 16;  // 16-column blocks in this pass (1..4)
         static const int nbw_env = getenv("FR_DECODE_NBW") ? atoi(getenv("FR_DECODE_NBW")) : 0;
         int nbw = nbt == 1 ? 1 : 2;                     // column blocks per work item
         if (nbw_env == 4 && nbt > 2) nbw = 4;
         a.halves = (nbt + nbw - 1) / nbw;
         // the model's own basis shape (199 + 29 coefficients = 13 + 2 groups) takes the fully unrolled ring schedule
-        static const bool loop_env = getenv("FR_DECODE_IMPL") && !strcmp(getenv("FR_DECODE_IMPL"), "loop");
-        const bool ring = !loop_env && groups_of(n_shape) == 13 && groups_of(n_exp) == 2 && nbw <= 2;
+        const bool ring = ring_shape && nbw <= 2;
         int rc;
         if (ring && nbw == 1) rc = launch_decode_ring<13, 2, 8, 1, 16>(a, lds, cus, tiles, stream);
         else if (ring) rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);
@@ -627,6 +640,7 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
                  : nbw == 2 ? launch_decode_nbw<2, 16>(a, lds, cus, tiles, stream)
                             : launch_decode_nbw<4, 12>(a, lds, cus, tiles, stream);
         if (rc != FR_OK) return rc;
+        b0 += MAXB;
     }
     return FR_OK;
 }

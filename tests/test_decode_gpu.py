@@ -45,7 +45,10 @@ def test_golden_small(small_assets):
     (7, 9, 1, 1, 1),         # N=63 (< 4 tiles, ragged last tile), single components
     (13, 17, 199, 29, 17),   # real component counts (the ring-scheduled kernel), B not a multiple of 16
     (12, 31, 199, 29, 5),    # ring kernel, one column block (16-column items)
-    (10, 23, 199, 29, 133),  # ring kernel, three passes: 64 + 64 + 5 columns
+    (10, 23, 199, 29, 133),  # ring kernel: one 128-column pass + 5 columns
+    (8, 21, 199, 29, 128),   # exactly one 128-column pass
+    (7, 15, 199, 29, 70),    # 128-column pass with 70 live columns (second half nearly empty)
+    (6, 11, 199, 29, 300),   # two wide passes + 44 columns
     (15, 16, 200, 17, 40),   # 13 + 2 groups again (200 -> 13, 17 -> 2) with different paddings
     (11, 19, 33, 16, 64),
     (9, 10, 40, 7, 65),      # > 64 columns: second pass
