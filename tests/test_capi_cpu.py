@@ -160,3 +160,19 @@ def test_ring_decode_kernel_keeps_its_stream_in_registers():
     for b in ring:
         assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", b), b[:400]
         assert re.search(r"VGPRs Spill: 0\b", b), b[:400]
+    # the requests take their base address from an SGPR pair handed to inline asm: the compiler's hazard recogniser does
+    # not look inside asm, so an SGPR written by a VALU instruction (v_readfirstlane / v_readlane) must not feed a request
+    # within the 5 wait states gfx9 demands -- the addresses have to be pure SALU arithmetic
+    asm_out = subprocess.run(cmd[:-4] + ["-S", "-o", "-", src], cwd=h._CSRC, capture_output=True, text=True)
+    assert asm_out.returncode == 0, asm_out.stderr[-2000:]
+    lines = asm_out.stdout.split("\n")
+    starts = [i for i, l in enumerate(lines) if l.startswith("_ZN2fr18decode_ring_kernel")]
+    ends = [i for i, l in enumerate(lines) if l.startswith(".Lfunc_end")]
+    assert len(starts) >= 2
+    for si in starts:
+        body = lines[si:min(e for e in ends if e > si)]
+        loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l and ", s[" in l]
+        valu_sgpr = [i for i, l in enumerate(body) if "v_readfirstlane" in l or "v_readlane" in l]
+        assert len(loads) >= 48
+        for li in loads:
+            assert all(not (0 < li - r <= 8) for r in valu_sgpr), (lines[si][:80], li)
