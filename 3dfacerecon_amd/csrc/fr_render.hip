@@ -73,6 +73,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// three consecutive floats as ONE 12-byte store (global_store_dwordx3): a scattered per-pixel normal costs one
+// cache-line transaction per lane instead of three, and a lane-contiguous plane write one instruction instead of three
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ void store3(float* p, float x, float y, float z) {
+    *reinterpret_cast<f32x3u*>(p) = (f32x3u){x, y, z};
+}
+
 // One triangle against one strip [r0, r1): the reference's per-triangle body (render_depth_op.cc:201-219, 263-316)
 // with the depth test replaced by the packed-key LDS max.
 // WINNER = false: resolve (LDS max).  WINNER = true: second pass -- the pixels whose resolved key is this triangle's
@@ -119,9 +126,7 @@ __device__ __forceinline__ void raster_triangle_into_strip(int t, const float* _
                 atomicMax(kp, key);
             } else if (*kp == key) {
                 float* np = nplane + (size_t)nstride * ((size_t)(y - r0) * W + x);
-                np[0] = nval.x;
-                np[1] = nval.y;
-                np[2] = nval.z;
+                store3(np, nval.x, nval.y, nval.z);
             }
         }
         if (++x > x_max) { x = x_min; y++; }
@@ -224,14 +229,9 @@ __device__ __forceinline__ void write_strip_fused(const RenderArgs& a, int b, in
                 dim[i] = fmaxf(d, 1e-6f);                                   // depthimg, network.py:199
                 float* o = nin + 7 * (size_t)i;
                 o[0] = clip01(d) * im[u];                                   // mask * im_gray, :195-196
-                o[1] = clip01(cov[u] ? tv[u].x : 0.0f);                     // pncc, :185
-                o[2] = clip01(cov[u] ? tv[u].y : 0.0f);
-                o[3] = clip01(cov[u] ? tv[u].z : 0.0f);
-                if (!cov[u]) {
-                    o[4] = 0.0f;
-                    o[5] = 0.0f;
-                    o[6] = 0.0f;
-                }
+                store3(o + 1, clip01(cov[u] ? tv[u].x : 0.0f), clip01(cov[u] ? tv[u].y : 0.0f),     // pncc, :185
+                       clip01(cov[u] ? tv[u].z : 0.0f));
+                if (!cov[u]) store3(o + 4, 0.0f, 0.0f, 0.0f);
             }
         }
     }
@@ -284,14 +284,10 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
                     dep[i] = cov[u] ? f32_unord((uint32_t)(kk[u] >> 32)) : bg_depth();
                     tin[i] = cov[u] ? (float)t[u] : -1.0f;
                     float* tp = txi + 3 * (size_t)i;
-                    tp[0] = cov[u] ? tv[u].x : 0.0f;
-                    tp[1] = cov[u] ? tv[u].y : 0.0f;
-                    tp[2] = cov[u] ? tv[u].z : 0.0f;
+                    store3(tp, cov[u] ? tv[u].x : 0.0f, cov[u] ? tv[u].y : 0.0f, cov[u] ? tv[u].z : 0.0f);
                     if (!cov[u]) {
                         float* np = nrm + 3 * (size_t)i;
-                        np[0] = 0.0f;
-                        np[1] = 0.0f;
-                        np[2] = 0.0f;
+                        store3(np, 0.0f, 0.0f, 0.0f);
                     }
                 }
             }
@@ -763,9 +759,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                                 const int bit = __ffs((int)won) - 1;
                                 won &= won - 1;
                                 float* np = nplane + NSTRIDE * (ptrdiff_t)(p0 + (bit >> 3) * W + (bit & 7));
-                                np[0] = nv.x;
-                                np[1] = nv.y;
-                                np[2] = nv.z;
+                                store3(np, nv.x, nv.y, nv.z);
                             }
                         }
                     }
