@@ -191,7 +191,7 @@ def main():
         # owns the vertex / triangle / texture reads, the resolve kernel the four output planes
         emit_bytes = (4.0 * 3 * N + (4.0 * 3 * T + 4.0 * 3 * N) / B) * B
         resolve_bytes = 4.0 * H * W * 8 * B
-        roof_decode = {"bound": "mfma", "kernel": "decode_ring_kernel<13,2,8,2,16> (fr_decode_3dmm)",
+        roof_decode = {"bound": "mfma", "kernel": "decode_ring_kernel<13,2,8,2,16,64> (fr_decode_3dmm)",
                        "achieved": flops / (decode_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "traffic": None, "avg_ms": decode_ms, "algorithmic_flop_per_launch": flops,
                        "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9}
