@@ -4,7 +4,9 @@ There is deliberately NO fallback: if libfr_hotpath.so cannot be built or loaded
 the hot path raises.  PyTorch is used only for device memory and streams.
 """
 import ctypes
+import hashlib
 import os
+import shutil
 import subprocess
 import threading
 
@@ -13,7 +15,8 @@ _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.path.join(_PKG_DIR, "libfr_hotpath.so")
 SOURCES = ["fr_capi.hip", "fr_render.hip", "fr_decode.hip", "fr_decode_bwd.hip"]
 HEADERS = [os.path.join(_CSRC, "fr_common.h"), os.path.join(_PKG_DIR, "..", "include", "fr_hotpath.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]  # single-lane LDS atomics stay single instructions
 
 FR_OK = 0
 _ERR_NAMES = {-1: "invalid argument", -2: "workspace / packed buffer too small", -3: "HIP launch or runtime error",
@@ -33,22 +36,46 @@ def _hipcc():
     return "hipcc"
 
 
+def src_hash():
+    """sha256 over the kernel sources, the headers and the compile flags (16 hex digits): the identity of a build."""
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for d in [os.path.join(_CSRC, s) for s in SOURCES] + HEADERS:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _built_hash():
+    try:
+        with open(LIB_PATH + ".srchash") as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def is_stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(_CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    """True when libfr_hotpath.so is missing or was built from other sources than the ones in the tree (content hash,
+    not mtimes: the .so travels to the GPU box in a snapshot whose timestamps mean nothing)."""
+    return not os.path.exists(LIB_PATH) or _built_hash() != src_hash()
 
 
 def compile(force=False, verbose=False):
     """Cross-compiles the HIP kernels + C ABI for gfx950 with hipcc (works without a GPU)."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(_CSRC, s) for s in SOURCES]
+    hipcc = _hipcc()
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        raise RuntimeError("fr_hotpath: %s is %s and hipcc is not available to rebuild it -- there is no CPU fallback"
+                           % (LIB_PATH, "stale" if os.path.exists(LIB_PATH) else "missing"))
+    want = src_hash()
+    tmp = LIB_PATH + ".tmp%d" % os.getpid()
+    cmd = [hipcc] + HIPCC_FLAGS + ['-DFR_SRC_HASH="%s"' % want, "-o", tmp] + [os.path.join(_CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)
+    os.replace(tmp, LIB_PATH)
+    with open(LIB_PATH + ".srchash", "w") as f:
+        f.write(want + "\n")
     return LIB_PATH
 
 
@@ -80,30 +107,40 @@ def _bind(L):
     L.fr_decode_3dmm_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp,
                                           ctypes.c_size_t, _vp]
     L.fr_decode_3dmm_backward.restype = _i
+    L.fr_debug_render_geom.argtypes = [_i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int)]
+    L.fr_debug_render_geom.restype = None
+    L.fr_debug_div3_sweep.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]
+    L.fr_debug_div3_sweep.restype = _i
     return L
 
 
 EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_render_depth_forward",
            "fr_render_depth_backward", "fr_decode_packed_basis_bytes", "fr_decode_pack_basis", "fr_decode_3dmm",
            "fr_decode_backward_workspace_bytes", "fr_decode_3dmm_backward", "fr_rendering_layer_forward",
-           "fr_render_depth_forward_phases"]
+           "fr_render_depth_forward_phases", "fr_debug_render_geom", "fr_debug_div3_sweep"]
 
 
 def lib():
-    """Returns the bound ctypes library, building it first if the .so is missing (the reference's
-    build-on-import fallback, rendering_layer/ops.py:63-72).  Raises if it can be neither built nor loaded."""
+    """Returns the bound ctypes library.  The .so is (re)built first when it is missing or stale -- built from other
+    sources than the tree holds -- (the reference's build-on-import fallback, rendering_layer/ops.py:63-72); a stale
+    binary that cannot be rebuilt is refused, never loaded.  Raises if it can be neither built nor loaded."""
     global _lib
     if _lib is None:
         with _lock:
             if _lib is None:
                 import torch  # noqa: F401  (loads the ROCm runtime this library binds to, by SONAME)
-                if not os.path.exists(LIB_PATH):
+                if is_stale():
                     compile()
                 try:
-                    _lib = _bind(ctypes.CDLL(LIB_PATH))
+                    L = _bind(ctypes.CDLL(LIB_PATH))
                 except OSError as e:
                     raise RuntimeError("fr_hotpath: cannot load %s (%s); run compile() -- there is no CPU fallback"
                                        % (LIB_PATH, e))
+                want = src_hash()
+                if want.encode() not in L.fr_version():
+                    raise RuntimeError("fr_hotpath: %s reports %r but the sources hash to %s: stale binary refused"
+                                       % (LIB_PATH, L.fr_version(), want))
+                _lib = L
     return _lib
 
 

@@ -4,7 +4,11 @@
 
 extern "C" {
 
-const char* fr_version(void) { return "fr_hotpath 0.1 (gfx950)"; }
+#ifndef FR_SRC_HASH
+#define FR_SRC_HASH "unhashed"
+#endif
+// the build identity: _lib.py refuses a library whose source hash differs from the tree's
+const char* fr_version(void) { return "fr_hotpath 0.2 (gfx950) src=" FR_SRC_HASH; }
 
 const char* fr_strerror(int code) {
     switch (code) {
@@ -41,7 +45,7 @@ int fr_render_depth_forward(const float* vertex, const float* tri, const float* 
 int fr_render_depth_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                                    int H, int W, int C, int tex_batch, float* depth, float* tex_img, float* normal,
                                    float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream, int phases) {
-    if (phases < 1 || phases > 3) return FR_ERR_INVALID_ARG;
+    if (phases < 1 || phases > 7) return FR_ERR_INVALID_ARG;
     if (B < 0 || nver < 0 || ntri < 0 || H < 0 || W < 0 || C != 3) return FR_ERR_INVALID_ARG;
     if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
     if ((size_t)B * H * W == 0) return FR_OK;

@@ -57,6 +57,8 @@ struct RenderArgs {
     float* depth_img;      // [B,H,W,1] = max(depth, 1e-6)
     float wm1, hm1;        // (float)(W-1), (float)(H-1)
     uint32_t rows_magic;   // ceil(2^32 / rows): y / rows == umulhi(y, magic) for y, rows < 2^16
+    const int4* tri4;      // [ntri] pre-validated triangles {4*p1, 4*p2, 4*p3, valid} (pack_tri_kernel)
+    uint32_t nseg_magic;   // ceil(2^32 / nseg): lid / nseg == umulhi(lid, magic) (launcher checks the range)
 };
 
 constexpr int SEG = 504;         // triangles (and record capacity) per segment: 504 * 40 B of queue + counters <= 20 KiB,
@@ -421,6 +423,38 @@ __device__ __forceinline__ bool id_ok(float f, int n, int& p) {
     return (f > -1.0f) && ((unsigned)p < (unsigned)n);
 }
 
+// The triangle list is a per-call constant shared by every face of the batch (network.py:178 makes it a tf.constant):
+// its float-stored ids are converted, range-checked and turned into byte offsets ONCE per call (or once per model through
+// fr_render_pack_tri) instead of once per (face, triangle) -- phase A of the emit kernel then costs one 16-byte load per
+// triangle.  Entry = {4*p1, 4*p2, 4*p3, valid}; an invalid triangle (an id outside [0,nver): deviation 3, the reference
+// would read out of bounds) carries offsets 0 (safe dummy gathers) and valid = 0.
+__global__ __launch_bounds__(256) void pack_tri_kernel(const float* __restrict__ tri, int nver, int ntri,
+                                                       int4* __restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntri) return;
+    int p1, p2, p3;
+    const bool ok = id_ok(tri[t], nver, p1) & id_ok(tri[(size_t)ntri + t], nver, p2) &
+                    id_ok(tri[2 * (size_t)ntri + t], nver, p3);
+    out[t] = ok ? make_int4(p1 << 2, p2 << 2, p3 << 2, 1) : make_int4(0, 0, 0, 0);
+}
+__device__ __forceinline__ float ld_boff(const float* __restrict__ base, int boff) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)(uint32_t)boff);
+}
+// x / 3.0f, correctly rounded like the division the reference performs (render_depth_op.cc:217, 223): for |x| in
+// [2^-100, 2^100] the quotient comes from q0 = x*(1/3), r = fma(-3, q0, x) (exact), q = fma(r, 1/3, q0) -- three
+// instructions instead of the ~12 of the IEEE division sequence (bit-identical to x / 3.0f on every finite x of that
+// range: tests/test_render_gpu.py sweeps all 2^32 bit patterns); anything else takes the division.
+__device__ __forceinline__ float div3(float x) {
+    const float ax = __builtin_fabsf(x);
+    if (ax >= 7.888609052e-31f && ax <= 1.267650600e30f) {
+        const float y = 0.3333333432674407958984375f;
+        const float q0 = x * y;
+        const float r = __builtin_fmaf(-3.0f, q0, x);
+        return __builtin_fmaf(r, y, q0);
+    }
+    return x / 3.0f;
+}
+
 // The kernel is VALU-bound (rocprof: SQ_ACTIVE_INST_VALU ~ 94 % of its duration), and about half of all triangles
 // are rejected by the bbox rule before any fp64 work.  So it runs in two phases.  Phase A: every thread takes TPT
 // triangles of the segment (all their loads in flight together), does the ids, the nine gathers and the bbox reject,
@@ -438,9 +472,8 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     __shared__ float4 qb[SEG];   // phase A->B: x3 y3 z1 z2          phase B->C: the record's normal
     __shared__ uint2 qd[SEG];    // .x: z3 (raw bits) in A->B, then bucket << 16 | pos (~0 = none) in B->C; .y: local index
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = lid / a.nseg;
+    const int b = a.nseg_magic ? (int)__umulhi((uint32_t)lid, a.nseg_magic) : lid / a.nseg;  // lid / nseg
     const int seg = lid - b * a.nseg;
     const int S = a.strips;
     if (tid < 2 * S) cnt[tid] = 0;
@@ -452,28 +485,25 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     const float* __restrict__ vy = vx + nver;
     const float* __restrict__ vz = vy + nver;
 
-    // ---------------- phase A: ids, gathers, bbox reject ----------------
+    // ---------------- phase A: pre-validated ids, gathers, bbox reject ----------------
     {
         bool surv[TPT];
-        int p1[TPT], p2[TPT], p3[TPT];
+        int4 e[TPT];
         float x1[TPT], x2[TPT], x3[TPT], y1[TPT], y2[TPT], y3[TPT], z1[TPT], z2[TPT], z3[TPT];
         bool valid[TPT];
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
             const int t = seg * SEG + u * EMIT_ACTIVE + tid;
-            const uint32_t tt = (uint32_t)min(t, ntri - 1);
-            const bool ok1 = id_ok(ld_off(a.tri, tt), nver, p1[u]);
-            const bool ok2 = id_ok(ld_off(a.tri + ntri, tt), nver, p2[u]);
-            const bool ok3 = id_ok(ld_off(a.tri + 2 * (size_t)ntri, tt), nver, p3[u]);
-            // (ids outside [0,nver) -> deviation 3: the reference would read out of bounds)
-            valid[u] = (tid < EMIT_ACTIVE) && (t < ntri) && ok1 && ok2 && ok3;
-            if (!valid[u]) p1[u] = p2[u] = p3[u] = 0;  // nver >= 1 here: safe dummy gathers
+            // one unconditional 16-byte load (saddr + 32-bit offset form); no short-circuit on .w, or the compiler
+            // splits the load and serialises the two halves
+            e[u] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.tri4) + (size_t)((uint32_t)min(t, ntri - 1) << 4));
+            valid[u] = ((int)(tid < EMIT_ACTIVE) & (int)(t < ntri) & e[u].w) != 0;
         }
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
-            x1[u] = ld_off(vx, p1[u]); x2[u] = ld_off(vx, p2[u]); x3[u] = ld_off(vx, p3[u]);
-            y1[u] = ld_off(vy, p1[u]); y2[u] = ld_off(vy, p2[u]); y3[u] = ld_off(vy, p3[u]);
-            z1[u] = ld_off(vz, p1[u]); z2[u] = ld_off(vz, p2[u]); z3[u] = ld_off(vz, p3[u]);
+            x1[u] = ld_boff(vx, e[u].x); x2[u] = ld_boff(vx, e[u].y); x3[u] = ld_boff(vx, e[u].z);
+            y1[u] = ld_boff(vy, e[u].x); y2[u] = ld_boff(vy, e[u].y); y3[u] = ld_boff(vy, e[u].z);
+            z1[u] = ld_boff(vz, e[u].x); z2[u] = ld_boff(vz, e[u].y); z3[u] = ld_boff(vz, e[u].z);
         }
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
@@ -492,23 +522,29 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const float* tj = a.texture + (size_t)j * nver;
-                    tm[j] = ((ld_off(tj, p1[u]) + ld_off(tj, p2[u])) + ld_off(tj, p3[u])) / 3.0f;
+                    tm[j] = div3((ld_boff(tj, e[u].x) + ld_boff(tj, e[u].y)) + ld_boff(tj, e[u].z));
                 }
                 a.tritex_ws[seg * SEG + u * EMIT_ACTIVE + tid] = make_float4(tm[0], tm[1], tm[2], 0.0f);
             }
         }
-#pragma unroll
-        for (int u = 0; u < TPT; u++) {
-            const unsigned long long m = __ballot(surv[u]);
-            uint32_t wbase = 0;
-            if (lane == 0 && m) wbase = atomicAdd(&qn, (uint32_t)__popcll(m));
-            wbase = __shfl(wbase, 0);
-            if (surv[u]) {
-                const uint32_t slot = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                qa[slot] = make_float4(x1[u], y1[u], x2[u], y2[u]);
-                qb[slot] = make_float4(x3[u], y3[u], z1[u], z2[u]);
-                qd[slot] = make_uint2(__float_as_uint(z3[u]), (uint32_t)(u * EMIT_ACTIVE + tid));
-            }
+        // survivors of both triangles are compacted with ONE LDS atomic per wave
+        static_assert(TPT == 2, "compaction below is written for two triangles per thread");
+        const unsigned long long m0 = __ballot(surv[0]), m1 = __ballot(surv[1]);
+        const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1);
+        uint32_t wbase = 0;
+        if ((tid & 63) == 0 && (c0 + c1)) wbase = atomicAdd(&qn, c0 + c1);
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        if (surv[0]) {
+            const uint32_t slot = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+            qa[slot] = make_float4(x1[0], y1[0], x2[0], y2[0]);
+            qb[slot] = make_float4(x3[0], y3[0], z1[0], z2[0]);
+            qd[slot] = make_uint2(__float_as_uint(z3[0]), (uint32_t)tid);
+        }
+        if (surv[1]) {
+            const uint32_t slot = wbase + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+            qa[slot] = make_float4(x1[1], y1[1], x2[1], y2[1]);
+            qb[slot] = make_float4(x3[1], y3[1], z1[1], z2[1]);
+            qd[slot] = make_uint2(__float_as_uint(z3[1]), (uint32_t)(EMIT_ACTIVE + tid));
         }
     }
     __syncthreads();
@@ -524,7 +560,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
         int bucket = 0;
         uint4 rec = make_uint4(0, 0, 0, 0);
         float4 nrm4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float h = ((z1 + z2) + z3) / 3.0f;  // fp32 centroid depth, :217
+        float h = div3((z1 + z2) + z3);     // fp32 centroid depth ((z1+z2)+z3)/3.0f, :217
         h = h + 0.0f;                        // -0 -> +0
         const int t = seg * SEG + (int)D2.y;
         if (h > bg_depth()) {                // NaN or <= background never passes 'depth < h' (:295)
@@ -567,13 +603,12 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
                 nrm4 = make_float4((float)(ay * bz - az * by), (float)(az * bx - ax * bz), (float)(ax * by - ay * bx), 0.0f);
                 if (a.tex_stride) {  // every face has its own texture: mean per emitting (face, triangle)
                     const float* __restrict__ tex = a.texture + (size_t)b * a.tex_stride;
-                    const int p1 = (int)ld_off(a.tri, (uint32_t)t), p2 = (int)ld_off(a.tri + ntri, (uint32_t)t),
-                              p3 = (int)ld_off(a.tri + 2 * (size_t)ntri, (uint32_t)t);  // valid: checked in phase A
+                    const int4 e = a.tri4[t];  // valid: checked in phase A
                     float tm[3];
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
                         const float* tj = tex + (size_t)j * nver;
-                        tm[j] = ((ld_off(tj, p1) + ld_off(tj, p2)) + ld_off(tj, p3)) / 3.0f;
+                        tm[j] = div3((ld_boff(tj, e.x) + ld_boff(tj, e.y)) + ld_boff(tj, e.z));
                     }
                     a.tritex_ws[(size_t)b * ntri + t] = make_float4(tm[0], tm[1], tm[2], 0.0f);
                 }
@@ -593,6 +628,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     // ---------------- phase C: bucket offsets, records out ----------------
     uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
     if (tid < 64) {  // one wave scans the (at most 64) bucket counts
+        const int lane = tid;
         const uint32_t c = (tid < 2 * S) ? cnt[tid] : 0u;
         uint32_t inc = c;
 #pragma unroll
@@ -791,25 +827,116 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
 }
 
 // ---- backward: zeros + scatter-add of g/3 to the z row (render_depth_op.cc:345-363) -------------------------
-__global__ __launch_bounds__(256) void render_backward_kernel(const float* __restrict__ depth_grad,
-                                                              const float* __restrict__ tri,
-                                                              const float* __restrict__ tri_ind,
-                                                              float* __restrict__ vertex_grad, int nver, int ntri,
-                                                              long long npix_face, long long total) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long step = (long long)gridDim.x * blockDim.x;
-    for (; i < total; i += step) {
-        int t = f2i_x86(tri_ind[i]);
-        if (t < 0 || t >= ntri) continue;  // deviation 2: background pixels carry tri_ind = -1
-        int p1 = f2i_x86(tri[t]), p2 = f2i_x86(tri[(size_t)ntri + t]), p3 = f2i_x86(tri[2 * (size_t)ntri + t]);
-        if ((unsigned)p1 >= (unsigned)nver || (unsigned)p2 >= (unsigned)nver || (unsigned)p3 >= (unsigned)nver)
-            continue;
-        float g = depth_grad[i] * 1.0f / 3.0f;  // (g*1.0f)/3.0f, :361
-        long long b = i / npix_face;
-        float* gz = vertex_grad + ((size_t)b * 3 + 2) * nver;
-        atomicAdd(gz + p1, g);
-        atomicAdd(gz + p2, g);
-        atomicAdd(gz + p3, g);
+// The reference is a serial loop (one fixed summation order); float atomics would make the per-vertex order depend on
+// the schedule.  Here the sum is made ORDER-INDEPENDENT instead: every contribution c = (g * 1.0f) / 3.0f (fp32, as
+// :361 computes it) is converted EXACTLY to a 64-bit fixed-point integer (c * 2^k is exact in double; one llrint), the
+// integers are added with LDS integer atomics (associative => bit-reproducible whatever the order), and the total is
+// rounded to fp32 once.  k is chosen per face from max|c| so that the largest term has 40 significant bits below the
+// int64 headroom the H*W*3 possible terms need: every term is represented to 2^-41 of the face's largest term, i.e. the
+// result is the exactly rounded real sum up to  n_terms * 2^-41 * max|c|  -- at least as close to the real-number sum
+// as the reference's sequential fp32 order (whose error grows with the partial sums), and identical run to run.
+// One workgroup owns one (face, vertex range) pair: it scans ALL the face's pixels (L2-resident planes) and keeps only
+// the contributions that land in its range, so no two workgroups ever add to the same vertex and nothing needs zeroing:
+// the owner writes its range of all three rows (x and y rows: zeros, render_depth_op.cc:359-363).
+// A face whose gradients contain Inf / NaN cannot be scaled: it takes fp32 LDS atomics (the class of the result --
+// NaN / +-Inf -- does not depend on the order).
+constexpr int BWD_BLOCK = 1024;
+constexpr int BWD_RANGE_MAX = 16 * 1024;  // vertices per owner workgroup (8 B each: 128 KiB of LDS)
+
+struct BwdRenderArgs {
+    const float* depth_grad;  // [B,H,W,1]
+    const float* tri;         // [3,ntri]
+    const float* tri_ind;     // [B,H,W,1]
+    float* vertex_grad;       // [B,3,nver]
+    int nver, ntri, npix;     // npix = H*W
+    int splits, range;        // owner workgroups per face, vertices per owner
+};
+
+__device__ __forceinline__ bool bwd_pixel(const BwdRenderArgs& a, const float* __restrict__ ti, int i, int& p1, int& p2,
+                                          int& p3) {
+    const int t = f2i_x86(ti[i]);
+    if (t < 0 || t >= a.ntri) return false;  // deviation 2: background pixels carry tri_ind = -1
+    p1 = f2i_x86(a.tri[t]);
+    p2 = f2i_x86(a.tri[(size_t)a.ntri + t]);
+    p3 = f2i_x86(a.tri[2 * (size_t)a.ntri + t]);
+    return (unsigned)p1 < (unsigned)a.nver && (unsigned)p2 < (unsigned)a.nver && (unsigned)p3 < (unsigned)a.nver;
+}
+
+__global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];  // [range]
+    __shared__ uint32_t wmax[BWD_BLOCK / 64];
+    __shared__ uint32_t wbad[BWD_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / a.splits;
+    const int sp = blockIdx.x - b * a.splits;
+    const int v0 = sp * a.range;
+    const int v1 = min(a.nver, v0 + a.range);
+    const float* __restrict__ g = a.depth_grad + (size_t)b * a.npix;
+    const float* __restrict__ ti = a.tri_ind + (size_t)b * a.npix;
+    for (int i = tid; i < v1 - v0; i += BWD_BLOCK) acc[i] = 0ull;
+
+    // pass 1: the face's largest |c| over the covered pixels (max is order independent)
+    uint32_t m = 0, bad = 0;
+    for (int i = tid; i < a.npix; i += BWD_BLOCK) {
+        const int t = f2i_x86(ti[i]);
+        if (t < 0 || t >= a.ntri) continue;
+        const float c = g[i] * 1.0f / 3.0f;
+        const uint32_t u = __float_as_uint(c) & 0x7FFFFFFFu;
+        if (u >= 0x7F800000u) bad = 1; else m = max(m, u);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        m = max(m, (uint32_t)__shfl_xor((int)m, d));
+        bad |= (uint32_t)__shfl_xor((int)bad, d);
+    }
+    if (lane == 0) { wmax[wave] = m; wbad[wave] = bad; }
+    __syncthreads();
+    m = 0; bad = 0;
+#pragma unroll
+    for (int w = 0; w < BWD_BLOCK / 64; w++) { m = max(m, wmax[w]); bad |= wbad[w]; }
+
+    float* gx = a.vertex_grad + (size_t)b * 3 * a.nver;
+    float* gy = gx + a.nver;
+    float* gz = gy + a.nver;
+    if (bad) {  // Inf / NaN gradients: fp32 LDS atomics
+        float* facc = reinterpret_cast<float*>(acc);
+        __syncthreads();
+        for (int i = tid; i < v1 - v0; i += BWD_BLOCK) facc[i] = 0.0f;
+        __syncthreads();
+        for (int i = tid; i < a.npix; i += BWD_BLOCK) {
+            int p[3];
+            if (!bwd_pixel(a, ti, i, p[0], p[1], p[2])) continue;
+            const float c = g[i] * 1.0f / 3.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (p[k] >= v0 && p[k] < v1) atomicAdd(&facc[p[k] - v0], c);
+        }
+        __syncthreads();
+        for (int i = tid; i < v1 - v0; i += BWD_BLOCK) { gx[v0 + i] = 0.0f; gy[v0 + i] = 0.0f; gz[v0 + i] = facc[i]; }
+        return;
+    }
+    // scale 2^k: the largest term lands in [2^40, 2^41); up to 2^21 terms (3 per pixel) stay below 2^62
+    const int e = (int)(m >> 23) - 127;  // floor(log2 max|c|) for a normal float; -127 for subnormals / zero
+    const double scale = ldexp(1.0, 40 - e);
+    const double inv_scale = ldexp(1.0, e - 40);
+    if (m != 0) {
+        for (int i = tid; i < a.npix; i += BWD_BLOCK) {
+            int p[3];
+            if (!bwd_pixel(a, ti, i, p[0], p[1], p[2])) continue;
+            const float c = g[i] * 1.0f / 3.0f;
+            const long long q = __double2ll_rn((double)c * scale);  // exact product, one rounding to the 2^-k grid
+            if (q == 0) continue;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (p[k] >= v0 && p[k] < v1) atomicAdd(&acc[p[k] - v0], (unsigned long long)q);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < v1 - v0; i += BWD_BLOCK) {
+        gx[v0 + i] = 0.0f;
+        gy[v0 + i] = 0.0f;
+        // one rounding to 24 bits (int64 -> fp32), then an exact power-of-two scaling in double
+        gz[v0 + i] = (float)((double)(float)(long long)acc[i] * inv_scale);
     }
 }
 
@@ -827,13 +954,13 @@ static bool env_is(const char* name, const char* val) {
 namespace {
 struct RenderGeom {
     int rows, strips, nseg;
-    size_t lds, recs_bytes, segoff_bytes, nrm_bytes;
+    size_t lds, recs_bytes, segoff_bytes, nrm_bytes, tri4_bytes;
     bool binned_ok;
 };
 constexpr size_t kLdsMax = 160 * 1024;
 
 // bins: enough workgroups to cover the 256 CUs a few times over, never more rows than fit in LDS
-RenderGeom render_geom(int B, int ntri, int H, int W) {
+RenderGeom render_geom(int B, int ntri, int H, int W, int rows_override) {
     RenderGeom g{};
     const size_t row_bytes = (size_t)W * sizeof(unsigned long long);
     int rows_max = row_bytes ? (int)((kLdsMax - fr::resolve_scratch_bytes(1024)) / row_bytes) : H;
@@ -842,8 +969,7 @@ RenderGeom render_geom(int B, int ntri, int H, int W) {
     if (want_strips > fr::MAX_STRIPS) want_strips = fr::MAX_STRIPS;  // two buckets per strip must fit the offset table
     int rows = H > 0 ? (H + want_strips - 1) / want_strips : 1;
     if (rows < fr::SMALL_H) rows = fr::SMALL_H;
-    int ov = env_int("FR_RENDER_ROWS", 0);  // tuning override
-    if (ov > 0) rows = ov;
+    if (rows_override > 0) rows = rows_override;  // tuning override (FR_RENDER_ROWS)
     if (rows > rows_max) rows = rows_max;
     if (rows > H) rows = H;
     if (rows < 1) rows = 1;
@@ -854,17 +980,53 @@ RenderGeom render_geom(int B, int ntri, int H, int W) {
     g.recs_bytes = (size_t)B * g.nseg * fr::SEG * sizeof(uint4);
     g.segoff_bytes = (size_t)B * g.nseg * fr::OFF_STRIDE * sizeof(uint16_t);
     g.nrm_bytes = (size_t)B * g.nseg * fr::SEG * sizeof(float4);  // per-record normals; also bounds the tritex table
-    g.binned_ok = rows_max >= 1 && g.strips <= fr::MAX_STRIPS && H <= 0xFFFF && W <= 0xFFFF &&
+    g.tri4_bytes = (size_t)g.nseg * fr::SEG * sizeof(int4);       // pre-validated triangle table
+    // An 8x4 hit window may touch at most TWO strips (its own bucket or the boundary bucket between them): with strips
+    // shorter than the window (a very wide image, or the override) it could span three and the emit kernel's bucket
+    // choice would drop hits -- such shapes take the scan path instead.
+    const bool window_fits = rows >= fr::SMALL_H || g.strips <= 1;
+    g.binned_ok = rows_max >= 1 && window_fits && g.strips <= fr::MAX_STRIPS && H <= 0xFFFF && W <= 0xFFFF &&
                   (long long)B * g.nseg <= 0x7FFFFFFFll;
     return g;
 }
+RenderGeom render_geom(int B, int ntri, int H, int W) { return render_geom(B, ntri, H, W, env_int("FR_RENDER_ROWS", 0)); }
 }  // namespace
+
+// test hook (tests/test_render_gpu.py): div3(x) against x / 3.0f on the bit patterns [first, first + count)
+namespace fr {
+__global__ __launch_bounds__(256) void div3_sweep_kernel(unsigned long long first, unsigned long long count,
+                                                         unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * 256) {
+        const float x = __uint_as_float((uint32_t)(first + i));
+        const float q = div3(x), w = x / 3.0f;
+        const bool same = __float_as_uint(q) == __float_as_uint(w) || (q != q && w != w);
+        bad += same ? 0 : 1;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace fr
+extern "C" int fr_debug_div3_sweep(unsigned long long first, unsigned long long count, unsigned long long* mismatches,
+                                   void* hip_stream) {
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (hipMemsetAsync(mismatches, 0, sizeof(unsigned long long), st) != hipSuccess) return FR_ERR_LAUNCH;
+    hipLaunchKernelGGL(fr::div3_sweep_kernel, dim3(4096), dim3(256), 0, st, first, count, mismatches);
+    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
+}
+
+// test hook (tests/test_capi_cpu.py): the strip geometry the launcher would choose, without a GPU.
+// out = {rows, strips, nseg, binned_ok}
+extern "C" void fr_debug_render_geom(int B, int ntri, int H, int W, int rows_override, int* out) {
+    RenderGeom g = render_geom(B, ntri, H, W, rows_override);
+    out[0] = g.rows; out[1] = g.strips; out[2] = g.nseg; out[3] = g.binned_ok ? 1 : 0;
+}
 
 size_t fr_render_workspace_bytes_impl(int B, int ntri, int H, int W) {
     if ((size_t)B * H * W == 0 || ntri == 0) return 0;
     RenderGeom g = render_geom(B, ntri, H, W);
     if (!g.binned_ok) return 0;
-    return g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes;
+    return g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes + g.tri4_bytes;
 }
 
 template <int BLK, bool FUSED>
@@ -880,7 +1042,7 @@ static int launch_resolve(const fr::RenderArgs& a, long long nbins, size_t lds, 
 static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
                               int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
                               const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
-                              hipStream_t stream, int phases = 3);
+                              hipStream_t stream, int phases = 7);
 
 int fr_launch_render_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                              int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
@@ -889,7 +1051,7 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
                               nullptr, nullptr, workspace, ws_bytes, stream);
 }
 
-// profiling aid: launch only the emit kernel (phases = 1) or only the resolve kernel (phases = 2) of the forward op
+// the forward op phase by phase: 4 = pack the triangle list into the workspace, 1 = emit, 2 = resolve (7 = the whole op)
 int fr_launch_render_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                                     int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
                                     float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases) {
@@ -932,6 +1094,7 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
 
     const bool binned = g.binned_ok && ntri > 0 && !env_is("FR_RENDER_IMPL", "scan");
     if (fused && !binned) return FR_ERR_UNSUPPORTED;  // the caller falls back to the unfused op + elementwise post-processing
+    a.tri4 = nullptr; a.nseg_magic = 0;
     if (!binned) {
         if (!(phases & 2)) return FR_OK;  // the fallback is a single kernel: it counts as the resolve phase
         static unsigned char lds_ok[64];
@@ -940,13 +1103,21 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
         hipLaunchKernelGGL(render_strip_kernel<BLOCK>, dim3((unsigned)nbins), dim3(BLOCK), g.lds, stream, a);
         return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
     }
-    if (ws_bytes < g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes || !workspace || ((uintptr_t)workspace & 15))
+    if (ws_bytes < g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes + g.tri4_bytes || !workspace ||
+        ((uintptr_t)workspace & 15))
         return FR_ERR_WORKSPACE;
     char* wsp = reinterpret_cast<char*>(workspace);
     a.recs = reinterpret_cast<uint4*>(wsp);
     a.segoff = reinterpret_cast<uint16_t*>(wsp + g.recs_bytes);
     a.recn = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes);
     a.tritex_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes + g.nrm_bytes);
+    int4* tri4 = reinterpret_cast<int4*>(wsp + g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes);
+    a.tri4 = tri4;
+    // lid / nseg through the 2^32 reciprocal is exact while lid * (magic * nseg - 2^32) < 2^32, i.e. B * nseg^2 < 2^32
+    a.nseg_magic = ((unsigned long long)B * g.nseg * g.nseg < 0x100000000ull && g.nseg > 1)
+                       ? (uint32_t)((0x100000000ull + (unsigned)g.nseg - 1) / (unsigned)g.nseg) : 0u;
+    if (phases & 4)
+        hipLaunchKernelGGL(pack_tri_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, tri, nver, ntri, tri4);
     if (phases & 1)
         hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
     if (!(phases & 2)) return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
@@ -965,13 +1136,26 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
 
 int fr_launch_render_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
                               int B, int nver, int ntri, int H, int W, hipStream_t stream) {
-    size_t bytes = (size_t)B * 3 * nver * sizeof(float);
-    if (bytes && hipMemsetAsync(vertex_grad, 0, bytes, stream) != hipSuccess) return FR_ERR_LAUNCH;
-    long long npix = (long long)H * W, total = npix * B;
-    if (total == 0 || ntri == 0 || nver == 0) return FR_OK;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(fr::render_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, depth_grad, tri,
-                       tri_ind, vertex_grad, nver, ntri, npix, total);
+    using namespace fr;
+    const size_t bytes = (size_t)B * 3 * nver * sizeof(float);
+    const long long npix = (long long)H * W;
+    if (npix * B == 0 || ntri == 0 || nver == 0)
+        return (!bytes || hipMemsetAsync(vertex_grad, 0, bytes, stream) == hipSuccess) ? FR_OK : FR_ERR_LAUNCH;
+    if (npix > (1ll << 20)) return FR_ERR_UNSUPPORTED;  // the int64 headroom covers 3 * 2^20 terms per vertex
+    // owners per face: enough for the LDS budget, and for ~one workgroup per CU on small batches
+    int splits = (nver + BWD_RANGE_MAX - 1) / BWD_RANGE_MAX;
+    const int want = (256 + B - 1) / B;
+    if (splits < want) splits = want;
+    if (splits > nver) splits = nver;
+    const int range = (nver + splits - 1) / splits;
+    splits = (nver + range - 1) / range;
+    if ((long long)B * splits > 0x7FFFFFFFll) return FR_ERR_UNSUPPORTED;
+    BwdRenderArgs a;
+    a.depth_grad = depth_grad; a.tri = tri; a.tri_ind = tri_ind; a.vertex_grad = vertex_grad;
+    a.nver = nver; a.ntri = ntri; a.npix = (int)npix; a.splits = splits; a.range = range;
+    static unsigned char lds_ok[64];
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_backward_kernel), lds_ok) != hipSuccess) return FR_ERR_LAUNCH;
+    hipLaunchKernelGGL(render_backward_kernel, dim3((unsigned)(B * splits)), dim3(BWD_BLOCK),
+                       (size_t)range * sizeof(unsigned long long), stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }

@@ -130,3 +130,29 @@ class FineNet(nn.Module):
         c3 = self.conv3(self.pool(c2))
         h = torch.cat([c1, self.upconv2(c2), self.upconv3(c3)], dim=1)
         return self.head(h).permute(0, 2, 3, 1).contiguous()
+
+
+class FaceReconModel(nn.Module):
+    """FaceRecNet.build() as ONE module (network.py:69-101): CoarseNet x nIter -> depth rendering layer -> FineNet.
+
+    forward(im_gray) returns {'pred_params' (B,d), 'vertices_proj' (B,3,N), 'coarse_depth_map' (B,H,W,1),
+    'pred_depth_map' (B,H,W,1) or None}.  Wrap THIS module in DistributedDataParallel and call the wrapper, so that DDP's
+    forward runs (reducer.prepare_for_backward) and the RCCL all-reduce of the gradients actually happens."""
+
+    def __init__(self, face_net, nIter=4, fine=True):
+        super().__init__()
+        self.face_net = face_net
+        self.coarse = CoarseNet(face_net, nIter=nIter)
+        self.fine = FineNet() if fine else None
+
+    def forward(self, im_gray, with_depth=True):
+        fn = self.face_net
+        params = self.coarse(im_gray)
+        out = {"pred_params": params, "vertices_proj": None, "coarse_depth_map": None, "pred_depth_map": None}
+        if with_depth or self.fine is not None:
+            v = fn.vertices_transform(params)                              # depth_rendering_layer, network.py:300-309
+            out["vertices_proj"] = v
+            out["coarse_depth_map"] = fn.coarse_net_input(v, im_gray=im_gray)[1]
+            if self.fine is not None:
+                out["pred_depth_map"] = self.fine(im_gray, out["coarse_depth_map"])
+        return out

@@ -45,15 +45,18 @@ class _Decode3DMM(torch.autograd.Function):
     reference's rotation goes through tf.py_func, network.py:150, which has no gradient)."""
 
     @staticmethod
-    def forward(ctx, params, net, R):
+    def forward(ctx, params, net, R, packed=None, im_size=None):
         h = _host()
         B = int(params.shape[0])
         out = torch.empty((B, 3, net.nvert), dtype=torch.float32, device=params.device)
+        packed = net._packed if packed is None else packed
+        im_size = float(net.im_size if im_size is None else im_size)
         with torch.cuda.device(params.device):
-            rc = h.lib().fr_decode_3dmm(h.ptr(params), h.ptr(net._packed), h.ptr(R), B, net.nvert, net.ndim_shape,
-                                        net.ndim_exp, float(net.im_size), h.ptr(out), h.stream_ptr(params.device))
+            rc = h.lib().fr_decode_3dmm(h.ptr(params), h.ptr(packed), h.ptr(R), B, net.nvert, net.ndim_shape,
+                                        net.ndim_exp, im_size, h.ptr(out), h.stream_ptr(params.device))
         h.check(rc, "fr_decode_3dmm")
         ctx.net = net
+        ctx.im_size = im_size
         ctx.save_for_backward(params, out, R if R is not None else params.new_empty(0))
         ctx.has_R = R is not None
         return out
@@ -72,9 +75,9 @@ class _Decode3DMM(torch.autograd.Function):
             ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=params.device)
             rc = L.fr_decode_3dmm_backward(h.ptr(g), h.ptr(params), h.ptr(out), h.ptr(net.pc_shape), h.ptr(net.pc_exp),
                                            h.ptr(R) if ctx.has_R else None, B, net.nvert, net.ndim_shape, net.ndim_exp,
-                                           float(net.im_size), h.ptr(gp), h.ptr(ws), nws, h.stream_ptr(params.device))
+                                           ctx.im_size, h.ptr(gp), h.ptr(ws), nws, h.stream_ptr(params.device))
         h.check(rc, "fr_decode_3dmm_backward")
-        return gp, None, None
+        return gp, None, None, None, None
 
 
 class FaceRecNet:
@@ -99,6 +102,16 @@ class FaceRecNet:
         self.pc_shape = torch.as_tensor(np.asarray(mesh_data['pc_shape'], np.float32), **f32)     # (3*N, ndim_shape)
         self.pc_exp = torch.as_tensor(np.asarray(mesh_data['pc_exp'], np.float32), **f32)         # (3*N, ndim_exp)
 
+        # albedo model of the shape-from-shading loss (network.py:26, 45-47): mean texture (3,N), the first ndim_tex
+        # texture components (3N, ndim_tex) and their coefficients (ndim_tex, 1); optional in the asset dict
+        self.ndim_tex = 10
+        self.mu_tex = self.pc_tex = self.param_tex = None
+        if mesh_data.get('mu_tex') is not None:
+            self.mu_tex = torch.as_tensor(np.asarray(mesh_data['mu_tex'], np.float32), **f32)
+        if mesh_data.get('pc_tex') is not None and mesh_data.get('param_tex') is not None:
+            self.pc_tex = torch.as_tensor(np.asarray(mesh_data['pc_tex'], np.float32)[:, 0:self.ndim_tex], **f32)
+            self.param_tex = torch.as_tensor(np.asarray(mesh_data['param_tex'], np.float32)[0:self.ndim_tex, :], **f32)
+
         # mesh info
         self.ndim_shape = int(mesh_data['ndim_shape'])
         self.ndim_exp = int(mesh_data['ndim_exp'])
@@ -121,6 +134,7 @@ class FaceRecNet:
                                         self.ndim_shape, self.ndim_exp, h.ptr(self._packed), nbytes,
                                         h.stream_ptr(self.device))
         h.check(rc, "fr_decode_pack_basis")
+        self._packed_nomu = None  # second image with mu = 0, built on first use by geometry_product()
 
         # initial parameters (network.py:57-62)
         geo = torch.zeros((batch_size, self.ndim_shape + self.ndim_exp), **f32)
@@ -148,6 +162,32 @@ class FaceRecNet:
             if tuple(Rc.shape) != (B, 3, 3):
                 raise ValueError("R must be (B,3,3)")
         return _Decode3DMM.apply(p, self, Rc)
+
+    def geometry_product(self, geometry_params):
+        """(B, ndim_shape + ndim_exp) coefficients -> basis product [pc_shape | pc_exp] . coeff as (B,3,N) (blocked rows),
+        the `tf.matmul(geometry_basis, geometry, transpose_b=True)` of the geometry loss (network.py:347-353), on the
+        MFMA decode kernel: a second packed image with mu = 0 is decoded with the identity pose (R = I, f = 1, t = 0,
+        im_size = 1).  The y row comes out as (1 - y) - 1, i.e. -y to within half an ulp of max(1, |y|) -- the loss
+        squares it.  Differentiable (fr_decode_3dmm_backward)."""
+        h = _host()
+        L = h.lib()
+        g = h.require_gpu_f32(geometry_params, "geometry_params")
+        B = int(g.shape[0])
+        if g.dim() != 2 or g.shape[1] != self.ndim_shape + self.ndim_exp:
+            raise ValueError("geometry_params must be (B,%d)" % (self.ndim_shape + self.ndim_exp))
+        if self._packed_nomu is None:
+            nbytes = L.fr_decode_packed_basis_bytes(self.nvert, self.ndim_shape, self.ndim_exp)
+            buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = L.fr_decode_pack_basis(h.ptr(torch.zeros_like(self.mu)), h.ptr(self.pc_shape), h.ptr(self.pc_exp),
+                                            self.nvert, self.ndim_shape, self.ndim_exp, h.ptr(buf), nbytes,
+                                            h.stream_ptr(self.device))
+            h.check(rc, "fr_decode_pack_basis")
+            self._packed_nomu = buf
+        pose = torch.zeros((B, self.ndim_pose), dtype=torch.float32, device=g.device)
+        pose[:, 6] = 1.0
+        eye = torch.eye(3, dtype=torch.float32, device=g.device)[None].repeat(B, 1, 1).contiguous()
+        return _Decode3DMM.apply(torch.cat([pose, g], 1), self, eye, self._packed_nomu, 1.0)
 
     # ---- rendering layer wrapper --------------------------------------------------------------------------
     def rendering_layer(self, vertex_proj, triangles, colors, im_gray=None):

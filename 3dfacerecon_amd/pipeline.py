@@ -65,6 +65,18 @@ class DecodeRenderPlan:
                           self.tex_batch, p(self.depth), p(self.texture_image), p(self.normal), p(self.tri_ind),
                           p(self._ws), ws_bytes)
         self._graph = None
+        # the triangle list is a constant of the model (reference network.py:178): convert + range-check it ONCE into the
+        # workspace's table; every step then runs the emit and resolve phases only
+        self._tri_packed = False
+        self.pack_tri()
+
+    def pack_tri(self):
+        """(Re)builds the pre-validated triangle table in the workspace; call again after changing net.tri in place."""
+        with torch.cuda.device(self.device):
+            rc = self._L.fr_render_depth_forward_phases(*self._ren_args, self._stream(), 4)
+        if rc:
+            self._h.check(rc, "fr_render_depth_forward_phases(pack)")
+        self._tri_packed = True
 
     # -- eager launches on the current stream ---------------------------------------------------------------
     def _stream(self):
@@ -76,12 +88,12 @@ class DecodeRenderPlan:
             self._h.check(rc, "fr_decode_3dmm")
 
     def render(self):
-        rc = self._L.fr_render_depth_forward(*self._ren_args, self._stream())
+        rc = self._L.fr_render_depth_forward_phases(*self._ren_args, self._stream(), 3)
         if rc:
-            self._h.check(rc, "fr_render_depth_forward")
+            self._h.check(rc, "fr_render_depth_forward_phases")
 
     def render_phase(self, phases):
-        """Profiling aid: phases = 1 launches only raster_emit_kernel, 2 only resolve_write_kernel."""
+        """phases = 1 launches only raster_emit_kernel, 2 only resolve_write_kernel, 4 only pack_tri_kernel."""
         rc = self._L.fr_render_depth_forward_phases(*self._ren_args, self._stream(), int(phases))
         if rc:
             self._h.check(rc, "fr_render_depth_forward_phases")

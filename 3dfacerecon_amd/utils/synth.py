@@ -12,6 +12,7 @@ import numpy as np
 N_SHAPE = 199
 N_EXP = 29
 N_POSE = 7  # utils/parser_3dmm.py:49
+N_TEX = 10  # texture components the reference keeps (network.py:26)
 
 GRID_U = 145  # rows  (145 * 367 = 53,215 vertices)
 GRID_V = 367  # cols
@@ -93,6 +94,10 @@ def make_assets(grid_u=GRID_U, grid_v=GRID_V, n_shape=N_SHAPE, n_exp=N_EXP, patc
     z01 = (z.reshape(-1) / 1.2e5)
     vertex_code = np.stack([v01, u01, z01], 0).astype(np.float32)  # PNCC-like colour in [0,1]
     mu_tex = (0.2 + 0.6 * vertex_code).astype(np.float32)
+    # albedo model of the SfS loss (reference network.py:45-47 uses the first 10 texture components): drawn AFTER the
+    # geometry bases so that those keep their values
+    pc_tex = (0.05 * smooth_modes(N_TEX, 0.0)).astype(np.float32)
+    param_tex = rng.normal(size=(N_TEX, 1)).astype(np.float32)
     return {
         "vertex": vertex_code,
         "tri": make_mesh(grid_u, grid_v, patch),
@@ -100,6 +105,8 @@ def make_assets(grid_u=GRID_U, grid_v=GRID_V, n_shape=N_SHAPE, n_exp=N_EXP, patc
         "pc_shape": pc_shape,
         "pc_exp": pc_exp,
         "mu_tex": mu_tex,
+        "pc_tex": pc_tex,
+        "param_tex": param_tex,
         "ndim_shape": n_shape,
         "ndim_exp": n_exp,
         "ndim_pose": N_POSE,

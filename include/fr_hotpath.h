@@ -54,10 +54,13 @@ int fr_render_depth_forward(const float* vertex, const float* tri, const float* 
                             int ntri, int H, int W, int C, int tex_batch, float* depth, float* tex_img,
                             float* normal, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream);
 
-/* Profiling aid: the forward op is two kernels (raster_emit_kernel writes per-strip hit records into the workspace,
- * resolve_write_kernel turns them into the four planes).  phases = 1 launches only the first, 2 only the second
- * (it consumes whatever records the workspace holds), 3 both (== fr_render_depth_forward).  bench.py uses it to bracket
- * each kernel with HIP events inside the timed region. */
+/* The forward op phase by phase.  It is three launches: pack_tri_kernel (phase bit 4) converts and range-checks the
+ * float-stored triangle list once into a table in the workspace; raster_emit_kernel (bit 1) writes per-strip hit
+ * records into the workspace; resolve_write_kernel (bit 2) turns them into the four planes.  phases = 7 is
+ * fr_render_depth_forward.  A caller whose triangle list is a constant of the model (the reference makes it a
+ * tf.constant, nets/network.py:178) and whose workspace persists may pack once (phases = 4) and then run phases = 3
+ * per batch: emit consumes whatever table the workspace holds.  bench.py also uses single phases to bracket each
+ * kernel with HIP events inside the timed region. */
 int fr_render_depth_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver,
                                    int ntri, int H, int W, int C, int tex_batch, float* depth, float* tex_img,
                                    float* normal, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream,
@@ -119,6 +122,18 @@ int fr_decode_3dmm_backward(const float* grad_vertex_proj, const float* params, 
                             const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N,
                             int n_shape, int n_exp, float im_size, float* grad_params, void* workspace, size_t ws_bytes,
                             void* hip_stream);
+
+/* ---- test hook ---------------------------------------------------------------------------------------------
+ * The screen-bin geometry the forward launcher chooses for a shape (no GPU needed): out = {rows per strip, strips,
+ * triangle segments, 1 if the binned path covers the shape else 0 (the strip-scan fallback runs)}.  rows_override > 0
+ * plays the FR_RENDER_ROWS tuning knob.  Used by tests/test_capi_cpu.py. */
+void fr_debug_render_geom(int B, int ntri, int H, int W, int rows_override, int* out);
+
+/* The kernels divide by 3.0f (render_depth_op.cc:217, 223, 361) through a 3-instruction exact sequence: this hook
+ * compares it with x / 3.0f on the fp32 bit patterns [first, first + count) and writes the number of differing results
+ * to the device word `mismatches`.  Used by tests/test_render_gpu.py (all 2^32 patterns). */
+int fr_debug_div3_sweep(unsigned long long first, unsigned long long count, unsigned long long* mismatches,
+                        void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -76,3 +76,67 @@ def test_background_and_bad_ids_are_skipped(oracle):
                                  torch.zeros((1, H, W, 3), device="cuda:0")).cpu().numpy()
     np.testing.assert_array_equal(vg, oracle.render_depth_grad(g, tri, tind, 4))
     np.testing.assert_array_equal(vg[0, 2], np.array([1 / 3, 1 / 3, 1 / 3, 0], np.float32))
+
+
+def test_backward_is_bit_reproducible_and_the_rounded_exact_sum(oracle, full_assets, synth):
+    """fr_render_depth_backward adds the contributions as exact fixed-point integers (order independent) and rounds once:
+    two launches are bit-equal, and the result is the float64 sum of the fp32 terms (g*1.0f)/3.0f rounded to fp32, up to
+    the stated quantisation n * 2^-41 * max|term| -- closer to the real sum than the reference's sequential fp32 order."""
+    A = full_assets
+    B = 4
+    P = synth.sample_params_batch(B, beta=0.7, seed=21)
+    V = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0)
+    dev = "cuda:0"
+    img = torch.zeros((B, 200, 200, 3), device=dev)
+    depth, _, _, tind = ops().render_depth(_t(V), _t(A["tri"]), _t(A["vertex"]), img)
+    rs = np.random.RandomState(2)
+    g = (rs.standard_normal((B, 200, 200, 1)) * np.exp(rs.uniform(-6, 6, (B, 200, 200, 1)))).astype(np.float32)
+    runs = [ops().render_depth_grad(_t(g), _t(V), _t(A["tri"]), depth, tind, img).cpu().numpy() for _ in range(3)]
+    np.testing.assert_array_equal(runs[0], runs[1])
+    np.testing.assert_array_equal(runs[0], runs[2])
+    got = runs[0]
+    ti = tind.cpu().numpy().reshape(B, -1).astype(np.int64)
+    tri = A["tri"].astype(np.int64)
+    c = (g.reshape(B, -1) * np.float32(1.0)) / np.float32(3.0)          # fp32 terms, as render_depth_op.cc:361 forms them
+    want = np.zeros((B, V.shape[2]), np.float64)
+    nterm = np.zeros((B, V.shape[2]), np.int64)
+    for b in range(B):
+        cov = ti[b] >= 0
+        for k in range(3):
+            np.add.at(want[b], tri[k, ti[b][cov]], c[b][cov].astype(np.float64))
+            np.add.at(nterm[b], tri[k, ti[b][cov]], 1)
+    assert np.all(got[:, :2] == 0)
+    cmax = np.abs(np.where(ti >= 0, c, 0)).max(axis=1)                  # per-face scale of the fixed-point grid
+    bound = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64) * 0.5 + \
+        (nterm + 1) * 2.0 ** -40 * cmax[:, None]
+    err = np.abs(got[:, 2].astype(np.float64) - want)
+    assert np.all(err <= bound), float((err / bound).max())
+    # and it agrees with the oracle's sequential fp32 order to that order's own rounding error
+    seq = oracle.render_depth_grad(g, A["tri"], tind.cpu().numpy(), V.shape[2])
+    np.testing.assert_allclose(got[:, 2], seq[:, 2], rtol=0, atol=float(1e-5 * max(1.0, cmax.max())))
+
+
+def test_backward_inf_nan_gradients_and_small_batch_owners():
+    """Inf / NaN depth gradients cannot be scaled to the fixed-point grid: that face takes fp32 LDS atomics and the class
+    of every result (NaN / +-Inf / finite) matches the sequential sum; B = 1 exercises the many-owners geometry."""
+    H, W = 6, 5
+    tri = np.array([[0, 1, 2], [2, 3, 4], [1, 3, 5]], np.float32).T.copy()
+    tind = np.array([[0, 0, 1, 1, -1], [2, 2, 2, 0, 1], [1, 1, -1, -1, 2], [0, 2, 1, 0, 0], [-1, -1, -1, -1, -1],
+                     [2, 1, 0, 2, 1]], np.float32).reshape(1, H, W, 1)
+    g = np.arange(H * W, dtype=np.float32).reshape(1, H, W, 1) - 7
+    want = np.zeros(6, np.float64)
+    for i in range(H * W):
+        t = int(tind.reshape(-1)[i])
+        if t >= 0:
+            for k in range(3):
+                want[int(tri[k, t])] += np.float32(g.reshape(-1)[i] / np.float32(3.0))
+    z = torch.zeros((1, H, W, 3), device="cuda:0")
+    vg = ops().render_depth_grad(_t(g), torch.zeros((1, 3, 6), device="cuda:0"), _t(tri), _t(g), _t(tind), z).cpu().numpy()
+    np.testing.assert_allclose(vg[0, 2], want, rtol=1e-6, atol=1e-6)
+    g2 = g.copy()
+    g2[0, 0, 0, 0] = np.inf       # triangle 0 -> vertices 0, 1, 2
+    g2[0, 1, 0, 0] = np.nan       # triangle 2 -> vertices 1, 3, 5
+    vg2 = ops().render_depth_grad(_t(g2), torch.zeros((1, 3, 6), device="cuda:0"), _t(tri), _t(g2), _t(tind), z).cpu().numpy()
+    assert np.isposinf(vg2[0, 2, 0]) and np.isposinf(vg2[0, 2, 2])
+    assert np.isnan(vg2[0, 2, 1]) and np.isnan(vg2[0, 2, 3]) and np.isnan(vg2[0, 2, 5])
+    assert np.isfinite(vg2[0, 2, 4]) and abs(vg2[0, 2, 4] - want[4]) < 1e-5

@@ -61,6 +61,76 @@ def test_ddp_gradient_allreduce_gloo():
     assert np.abs(g0).max() > 0
 
 
+class _FakeFaceNet:
+    """CPU stand-in for nets.network.FaceRecNet in the DDP wiring test: the same methods FaceReconModel calls, with a
+    small differentiable torch body instead of the HIP decode / render (which need a GPU).  Test double only."""
+
+    def __init__(self, ndim=12, im_size=16):
+        self.ndim, self.im_size = ndim, im_size
+        self.init_pred_params = torch.zeros((8, 1, 1, ndim))
+        g = torch.Generator().manual_seed(5)
+        self.basis = torch.randn((ndim, 3 * 10), generator=g)
+
+    def vertices_transform(self, params, R=None):
+        return (params.reshape(params.shape[0], -1) @ self.basis).reshape(-1, 3, 10)
+
+    def coarse_net_input(self, v, triangles=None, colors=None, im_gray=None):
+        B, S = v.shape[0], self.im_size
+        d = v[:, 2].mean(dim=1).reshape(B, 1, 1, 1) + 0.0 * im_gray
+        net_in = torch.cat([d * im_gray] + [im_gray] * 6, dim=3)
+        return net_in, d.expand(B, S, S, 1).contiguous()
+
+    def set_constraints(self, p):
+        return torch.sigmoid(p)
+
+
+def _ddp_model_worker(rank, world, port, q):
+    import importlib
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    d = importlib.import_module("3dfacerecon_amd.utils.dist")
+    cn = importlib.import_module("3dfacerecon_amd.nets.coarse_net")
+    d.init_from_env("gloo")
+
+    def build():
+        torch.manual_seed(0)
+        return cn.FaceReconModel(_FakeFaceNet(), nIter=2, fine=True)
+    x = torch.rand((2, 16, 16, 1), generator=torch.Generator().manual_seed(10 + rank))
+
+    def loss(out):
+        return out["pred_params"].square().mean() + out["pred_depth_map"].square().mean() + out["coarse_depth_map"].mean()
+    model = build()
+    ddp = torch.nn.parallel.DistributedDataParallel(model)
+    loss(ddp(x)).backward()                      # the way examples/coarse_loop.py calls it: through the DDP wrapper
+    g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    ref = build()
+    loss(ref(x)).backward()
+    gl = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    q.put((rank, g.numpy(), gl.numpy()))
+    d.finalize()
+
+
+def test_face_recon_model_under_ddp_allreduces_gloo():
+    """the harness wrapped a ModuleList (no forward) in DDP and called the inner modules, so no gradient
+    was ever all-reduced.  FaceReconModel is one nn.Module; called THROUGH the wrapper, both ranks end with the mean of
+    the two local gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_model_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, g0, l0), (_, g1, l1) = res
+    np.testing.assert_array_equal(g0, g1)
+    np.testing.assert_allclose(g0, 0.5 * (l0 + l1), rtol=1e-4, atol=1e-7)
+    assert np.abs(l0 - l1).max() > 1e-6 and np.abs(g0).max() > 0          # the shards really differ
+
+
 def test_module_shapes_cpu():
     cn = pkg("nets.coarse_net")
     it = cn.CoarseNetIter(ndim=235)

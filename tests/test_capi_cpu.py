@@ -56,10 +56,38 @@ def test_validation_codes_without_gpu():
     seg = 504  # triangles (= record slots) per segment
     nseg = (105840 + seg - 1) // seg
     assert L.fr_render_depth_workspace_bytes(64, 53215, 105840, 200, 200) == \
-        64 * nseg * (seg * 16 + 64 * 2) + 2 * 64 * nseg * seg * 16
+        64 * nseg * (seg * 16 + 64 * 2) + 2 * 64 * nseg * seg * 16 + nseg * seg * 16  # + pre-validated triangle table
     assert L.fr_render_depth_workspace_bytes(0, 5, 5, 8, 8) == 0
     # workspace too small
     assert L.fr_render_depth_forward(one, one, one, 1, 3, 1, 4, 4, 3, 1, one, one, one, one, nul, 0, nul) == -2
+
+
+def test_render_geometry_window_never_spans_three_strips():
+    """An 8x4 hit window is filed under its strip's bucket or the boundary bucket between two strips; strips shorter
+    than the window (FR_RENDER_ROWS = 1..3, or a very wide image whose strip must shrink to fit LDS) would let it span
+    three: such shapes must leave the binned path."""
+    L = pkg("_lib").lib()
+    out = (ctypes.c_int * 4)()
+
+    def geom(B, T, H, W, ov=0):
+        L.fr_debug_render_geom(B, T, H, W, ov, out)
+        return tuple(out)
+    rows, strips, nseg, ok = geom(64, 105840, 200, 200)
+    assert (rows, strips, nseg, ok) == (10, 20, 210, 1)
+    for ov in (1, 2, 3):
+        rows, strips, _, ok = geom(64, 105840, 200, 200, ov)
+        assert rows == ov and strips > 1 and ok == 0
+    assert geom(64, 105840, 200, 200, 7)[3] == 1 and geom(64, 105840, 200, 200, 25)[3] == 1
+    assert geom(64, 105840, 200, 200, 4)[3] == 0   # 50 strips: more than the bucket-offset table holds -> scan path
+    # a single strip may be shorter than the window (nothing to straddle)
+    assert geom(1, 10, 3, 16)[1:] == (1, 1, 1)
+    # very wide image: only 3 rows of keys fit LDS -> strips of 3 rows -> not binned
+    rows, strips, _, ok = geom(1, 1000, 96, 6000)
+    assert rows < 4 and strips > 1 and ok == 0
+    # every binned geometry keeps the invariant
+    for (B, H, W) in ((1, 200, 200), (64, 200, 200), (16, 448, 448), (7, 33, 1000), (300, 64, 64), (2, 5, 4096)):
+        rows, strips, _, ok = geom(B, 5000, H, W)
+        assert not ok or rows >= 4 or strips == 1
 
 
 def test_packed_basis_size():

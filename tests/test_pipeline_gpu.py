@@ -26,8 +26,26 @@ def test_params_to_depth_bit_exact(oracle, full_assets, synth):
     want64 = oracle.render_depth(V64.astype(np.float32), A["tri"], A["vertex"][None], 200, 200)
     same = (want64[3] == got[3]) & (got[3] >= 0)
     assert same.mean() > 0.3
-    assert np.max(np.abs(got[0][same] - want64[0][same])) <= 1e-5 * 4   # fp32 ulp at |z|~100 is 7.6e-6
-    assert (want64[3] != got[3]).mean() < 2e-3                           # edge-ambiguous pixels only
+    d = np.abs(got[0][same].astype(np.float64) - want64[0][same].astype(np.float64))
+    report = {"pixels_compared": int(same.sum()), "max_abs_ddepth": float(d.max()),
+              "frac_within_1e-5": float((d <= 1e-5).mean()), "frac_bit_equal": float((d == 0).mean()),
+              "depth_abs_max": float(np.abs(want64[0][same]).max()),
+              "fp32_ulp_at_depth_max": float(np.spacing(np.float32(np.abs(want64[0][same]).max()))),
+              "tri_ind_disagree_frac": float((want64[3] != got[3]).mean())}
+    print("params->depth vs float64 decode:", report)
+    try:
+        import json, os
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(report, open("gpurun_out/parity_depth_vs_f64.json", "w"), indent=1)
+    except OSError:
+        pass
+    # north_star: fp32 depth within 1e-5 of the reference.  The reference decode is TF 1.2's fp32 matmul, whose bits
+    # cannot be observed here; against a float64 evaluation of the same formula an fp32 depth of magnitude ~100 (ulp
+    # 7.6e-6) is within 1e-5 on the bulk of the pixels and within 2 ulp everywhere (measured numbers: report above,
+    # profiles/round2_parity_depth_vs_f64.json).
+    assert report["frac_within_1e-5"] >= 0.95
+    assert report["max_abs_ddepth"] <= 2.0 * report["fp32_ulp_at_depth_max"] + 1e-12
+    assert report["tri_ind_disagree_frac"] < 2e-3                         # edge-ambiguous pixels only
 
 
 def test_rendering_layer_wrapper(full_assets, synth):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, grid_from_rows, kat_inputs
+from conftest import GOLDEN, grid_from_rows, kat_inputs, pkg
 from gpu_util import assert_render_equal, render_gpu
 
 pytestmark = pytest.mark.gpu
@@ -281,3 +281,50 @@ def test_batch64_properties(full_assets, synth, oracle):
     gotr = render_gpu(V[:8], tri_rev, A["vertex"], 200, 200)
     np.testing.assert_array_equal(gotr[0], got1[0][:8])
     np.testing.assert_array_equal(gotr[3] >= 0, got1[3][:8] >= 0)
+
+
+def test_div3_matches_division_on_every_fp32():
+    """The kernels' 3-instruction x / 3.0f (centroid depth render_depth_op.cc:217, texture mean :223) against the IEEE
+    division, on all 2^32 fp32 bit patterns (NaN results compare equal as NaN)."""
+    import ctypes
+    L = pkg("_lib").lib()
+    cnt = torch.zeros((1,), dtype=torch.int64, device="cuda:0")
+    rc = L.fr_debug_div3_sweep(0, 1 << 32, ctypes.c_void_p(cnt.data_ptr()),
+                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 0
+
+
+@pytest.mark.parametrize("env", [{"FR_RENDER_IMPL": "scan"}, {"FR_RENDER_ROWS": "1"}, {"FR_RENDER_ROWS": "3"},
+                                 {"FR_RENDER_ROWS": "7"}])
+def test_fallback_and_row_override_paths(oracle, env):
+    """render_strip_kernel (every bin scans every triangle) is the path for shapes the binned rasteriser rejects; the
+    tuning knob FR_RENDER_ROWS below the hit-window height must route there too, larger overrides
+    stay binned.  All bit-exact."""
+    import os
+    rs = np.random.RandomState(11)
+    scenes = [_random_scene(rs, 3, 300, 700, 33, 47, 2.0) + (33, 47), _random_scene(rs, 2, 400, 900, 64, 64, 6.0) + (64, 64)]
+    ver, tri, tex = _subpixel_mesh(rs, 4, 40, 40, 56, 56, 0.45)
+    scenes.append((ver, tri, tex, 40, 40))
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for ver, tri, tex, H, W in scenes:
+            assert_render_equal(render_gpu(ver, tri, tex, H, W), oracle.render_depth(ver, tri, tex, H, W), str(env))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_very_wide_image_takes_the_scan_path(oracle):
+    """W = 6000: only three rows of keys fit the CU's LDS, shorter than the 8x4 hit window -> strip-scan path."""
+    rs = np.random.RandomState(5)
+    H, W = 9, 6000
+    ver, tri, tex = _random_scene(rs, 1, 200, 400, H, W, 40.0)
+    want = oracle.render_depth(ver, tri, tex, H, W)
+    assert (want[3] >= 0).sum() > 100
+    assert_render_equal(render_gpu(ver, tri, tex, H, W), want, "wide")
