@@ -412,8 +412,12 @@ __device__ __forceinline__ void ring_wait(f32x4& slot) {
     else asm volatile("s_waitcnt vmcnt(7)" : "+v"(slot));
 }
 
-template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64>
-__global__ __launch_bounds__(DEC_WAVES * 64) void decode_ring_kernel(DecodeArgs a) {
+// WPE: waves per SIMD the register allocation is sized for (>= DEC_WAVES / 4).  A workgroup of fewer waves than that
+// leaves VGPRs free on purpose: the 8-wave form (WPE = 4: <= 128 VGPRs, half the register file) lets the render
+// kernels of the previous batch share the CU with the decode of the next one (pipeline.py, PipelinedPlan).
+template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64, int WPE = DEC_WAVES / 4>
+__global__ __launch_bounds__(DEC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void decode_ring_kernel(DecodeArgs a) {
     constexpr int DEC_BLOCK = DEC_WAVES * 64;
     constexpr int G = GS + GE;
     constexpr int F = 3 * (G + 1);  // fragments per item
@@ -581,15 +585,15 @@ static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int cus, size_
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
-template <int GS, int GE, int R, int NBW, int WAVES, int MB = 64>
+template <int GS, int GE, int R, int NBW, int WAVES, int MB = 64, int WPE = WAVES / 4>
 static int launch_decode_ring(const fr::DecodeArgs& a, size_t lds, int cus, size_t tiles, hipStream_t stream) {
     static unsigned char lds_ok[64];
-    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB>), lds_ok) !=
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE>), lds_ok) !=
         hipSuccess)
         return FR_ERR_LAUNCH;
     const int slots = WAVES / a.halves;
     const int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
-    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
@@ -633,7 +637,9 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
         // the model's own basis shape (199 + 29 coefficients = 13 + 2 groups) takes the fully unrolled ring schedule
         const bool ring = ring_shape && nbw <= 2;
         int rc;
+        const int waves_env = getenv("FR_DECODE_WAVES") ? atoi(getenv("FR_DECODE_WAVES")) : 16;  // read per call (probe / PipelinedPlan knob)
         if (ring && nbw == 1) rc = launch_decode_ring<13, 2, 8, 1, 16>(a, lds, cus, tiles, stream);
+        else if (ring && waves_env == 8) rc = launch_decode_ring<13, 2, 8, 2, 8, 64, 4>(a, lds, cus, tiles, stream);
         else if (ring) rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);
         else
             rc = nbw == 1   ? launch_decode_nbw<1, 16>(a, lds, cus, tiles, stream)

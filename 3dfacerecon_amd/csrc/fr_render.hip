@@ -467,7 +467,8 @@ constexpr int EMIT_ACTIVE = SEG / TPT; // threads that own triangles in phase A 
 
 __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     __shared__ uint32_t cnt[OFF_STRIDE];  // per-bucket record count; turned into the bucket's start offset in phase C
-    __shared__ uint32_t qn;
+    __shared__ unsigned long long qn2;  // survivors queued: low word = single-pixel ones (from slot 0 up), high word =
+                                        // multi-pixel ones (from slot SEG-1 down)
     __shared__ float4 qa[SEG];   // phase A->B: x1 y1 x2 y2          phase B->C: the record
     __shared__ float4 qb[SEG];   // phase A->B: x3 y3 z1 z2          phase B->C: the record's normal
     __shared__ uint2 qd[SEG];    // .x: z3 (raw bits) in A->B, then bucket << 16 | pos (~0 = none) in B->C; .y: local index
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     const int seg = lid - b * a.nseg;
     const int S = a.strips;
     if (tid < 2 * S) cnt[tid] = 0;
-    if (tid == 0) qn = 0;
+    if (tid == 0) qn2 = 0ull;
     __syncthreads();
 
     const int nver = a.nver, ntri = a.ntri;
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
 
     // ---------------- phase A: pre-validated ids, gathers, bbox reject ----------------
     {
-        bool surv[TPT];
+        bool surv[TPT], single[TPT];
         int4 e[TPT];
         float x1[TPT], x2[TPT], x3[TPT], y1[TPT], y2[TPT], y3[TPT], z1[TPT], z2[TPT], z3[TPT];
         bool valid[TPT];
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             const float fy0 = ceilf(fminf(fminf(y1[u], y2[u]), y3[u])), fy1 = floorf(fmaxf(fmaxf(y1[u], y2[u]), y3[u]));
             surv[u] = valid[u] && (fx0 >= 0.0f) && (fy0 >= 0.0f) && (fx1 <= a.wm1) && (fy1 <= a.hm1) && !(fx1 < fx0) &&
                       !(fy1 < fy0);
+            single[u] = (fx0 == fx1) && (fy0 == fy1);
             // per-triangle texture mean ((t1+t2)+t3)/3 in fp32 (render_depth_op.cc:223) when the texture is shared by the
             // batch: computed once, by face 0's workgroups, for every valid triangle
             if (a.tex_stride == 0 && b == 0 && valid[u]) {
@@ -527,31 +529,40 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
                 a.tritex_ws[seg * SEG + u * EMIT_ACTIVE + tid] = make_float4(tm[0], tm[1], tm[2], 0.0f);
             }
         }
-        // survivors of both triangles are compacted with ONE LDS atomic per wave
+        // Survivors of both triangles are compacted with ONE LDS atomic per wave, into a two-ended queue: bboxes holding a
+        // single pixel centre (~78 % on the BFM-scale mesh) fill it from the front, the others from the back.  Phase B's
+        // waves are then (nearly) homogeneous: the pixel loop of a wave runs as long as its LONGEST lane, and mixing one
+        // 2- or 4-pixel triangle into a wave of 1-pixel ones doubles that wave's fp64 work.
         static_assert(TPT == 2, "compaction below is written for two triangles per thread");
-        const unsigned long long m0 = __ballot(surv[0]), m1 = __ballot(surv[1]);
-        const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1);
-        uint32_t wbase = 0;
-        if ((tid & 63) == 0 && (c0 + c1)) wbase = atomicAdd(&qn, c0 + c1);
-        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-        if (surv[0]) {
-            const uint32_t slot = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-            qa[slot] = make_float4(x1[0], y1[0], x2[0], y2[0]);
-            qb[slot] = make_float4(x3[0], y3[0], z1[0], z2[0]);
-            qd[slot] = make_uint2(__float_as_uint(z3[0]), (uint32_t)tid);
-        }
-        if (surv[1]) {
-            const uint32_t slot = wbase + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-            qa[slot] = make_float4(x1[1], y1[1], x2[1], y2[1]);
-            qb[slot] = make_float4(x3[1], y3[1], z1[1], z2[1]);
-            qd[slot] = make_uint2(__float_as_uint(z3[1]), (uint32_t)(EMIT_ACTIVE + tid));
+        const unsigned long long ms0 = __ballot(surv[0] && single[0]), ms1 = __ballot(surv[1] && single[1]);
+        const unsigned long long mm0 = __ballot(surv[0] && !single[0]), mm1 = __ballot(surv[1] && !single[1]);
+        const uint32_t cs0 = (uint32_t)__popcll(ms0), cs1 = (uint32_t)__popcll(ms1);
+        const uint32_t cm0 = (uint32_t)__popcll(mm0), cm1 = (uint32_t)__popcll(mm1);
+        unsigned long long wb = 0;
+        if ((tid & 63) == 0 && (cs0 + cs1 + cm0 + cm1))
+            wb = atomicAdd(&qn2, ((unsigned long long)(cm0 + cm1) << 32) | (unsigned long long)(cs0 + cs1));
+        const uint32_t fbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wb);
+        const uint32_t bbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wb >> 32));
+#pragma unroll
+        for (int u = 0; u < TPT; u++) {
+            if (surv[u]) {
+                const unsigned long long m = single[u] ? (u ? ms1 : ms0) : (u ? mm1 : mm0);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint32_t slot = single[u] ? fbase + (u ? cs0 : 0u) + rank
+                                                : (uint32_t)(SEG - 1) - (bbase + (u ? cm0 : 0u) + rank);
+                qa[slot] = make_float4(x1[u], y1[u], x2[u], y2[u]);
+                qb[slot] = make_float4(x3[u], y3[u], z1[u], z2[u]);
+                qd[slot] = make_uint2(__float_as_uint(z3[u]), (uint32_t)(u * EMIT_ACTIVE + tid));
+            }
         }
     }
     __syncthreads();
 
     // ---------------- phase B: dense lanes, one surviving triangle each ----------------
-    const int nq = (int)qn;
-    for (int sl = tid; sl < nq; sl += EMIT_BLOCK) {
+    const unsigned long long q2 = qn2;
+    const int nqf = (int)(uint32_t)q2, nq = nqf + (int)(uint32_t)(q2 >> 32);
+    for (int qi = tid; qi < nq; qi += EMIT_BLOCK) {
+        const int sl = qi < nqf ? qi : SEG - 1 - (qi - nqf);  // front part, then the back part (densely packed lanes)
         const float4 A4 = qa[sl], B4 = qb[sl];
         const uint2 D2 = qd[sl];
         const float x1 = A4.x, y1 = A4.y, x2 = A4.z, y2 = A4.w, x3 = B4.x, y3 = B4.y;
@@ -644,7 +655,8 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     __syncthreads();
     uint4* R = a.recs + ((size_t)b * a.nseg + seg) * SEG;
     float4* Rn = a.recn + ((size_t)b * a.nseg + seg) * SEG;
-    for (int sl = tid; sl < nq; sl += EMIT_BLOCK) {
+    for (int qi = tid; qi < nq; qi += EMIT_BLOCK) {
+        const int sl = qi < nqf ? qi : SEG - 1 - (qi - nqf);
         const uint32_t tag = qd[sl].x;
         if (tag != 0xFFFFFFFFu) {
             const float4 r = qa[sl];
@@ -863,9 +875,11 @@ __device__ __forceinline__ bool bwd_pixel(const BwdRenderArgs& a, const float* _
 }
 
 __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArgs a) {
+    // all LDS is dynamic (the launcher raises the dynamic limit to the CU's full 160 KiB, which leaves no room for
+    // static objects): [range] accumulators, then two small per-wave reduction arrays
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];  // [range]
-    __shared__ uint32_t wmax[BWD_BLOCK / 64];
-    __shared__ uint32_t wbad[BWD_BLOCK / 64];
+    uint32_t* wmax = reinterpret_cast<uint32_t*>(acc + a.range);              // [BWD_BLOCK / 64]
+    uint32_t* wbad = wmax + BWD_BLOCK / 64;                                   // [BWD_BLOCK / 64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.splits;
     const int sp = blockIdx.x - b * a.splits;
@@ -1156,6 +1170,6 @@ int fr_launch_render_backward(const float* depth_grad, const float* tri, const f
     static unsigned char lds_ok[64];
     if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_backward_kernel), lds_ok) != hipSuccess) return FR_ERR_LAUNCH;
     hipLaunchKernelGGL(render_backward_kernel, dim3((unsigned)(B * splits)), dim3(BWD_BLOCK),
-                       (size_t)range * sizeof(unsigned long long), stream, a);
+                       (size_t)range * sizeof(unsigned long long) + 2 * (BWD_BLOCK / 64) * sizeof(uint32_t), stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }

@@ -249,3 +249,23 @@ def point_in_tri_op_batch(P):
     P = np.ascontiguousarray(P, dtype=np.float64)
     fn = lib().fr_oracle_point_in_tri_op
     return np.array([fn(*row) for row in P.tolist()], bool)
+
+
+def set_constraints(pred_params, im_size, ndim_pose=7, ndim_shape=199):
+    """numpy fp32 restatement of FaceRecNet.set_constraints (nets/network.py:204-218): sigmoid, then
+    angles -> [-1.5,1.5] (s*3-1.5), tx,ty -> [0,im_size] (s*im_size), tz -> 0 (s*0), f -> [0,1e-3] (s*1e-3),
+    shape -> [0,1e4] (s*1e4), expression -> [-1.5,1.5] (s*3-1.5).  pred_params: (..., d) float32.
+    The sigmoid is 1/(1+exp(-x)) in fp32 (TF 1.2's own kernel bits are not observable here: tests compare the HIP-side
+    torch.sigmoid to this within a few ulp, and this function bit-for-bit with tests/golden/set_constraints_ref.npz)."""
+    x = np.asarray(pred_params, np.float32)
+    with np.errstate(over="ignore"):
+        s = (np.float32(1.0) / (np.float32(1.0) + np.exp(-x))).astype(np.float32)
+    out = np.empty_like(s)
+    out[..., 0:3] = s[..., 0:3] * np.float32(3.0) - np.float32(1.5)
+    out[..., 3:5] = s[..., 3:5] * np.float32(im_size)
+    out[..., 5] = s[..., 5] * np.float32(0.0)
+    out[..., 6] = s[..., 6] * np.float32(1e-3)
+    ps = ndim_pose + ndim_shape
+    out[..., ndim_pose:ps] = s[..., ndim_pose:ps] * np.float32(1e4)
+    out[..., ps:] = s[..., ps:] * np.float32(3.0) - np.float32(1.5)
+    return out

@@ -8,6 +8,9 @@ What can be taken from the reference itself
     stand-in is written for it), so the two function definitions are pulled out of the parsed AST and executed
     in memory -- the reference's own code runs, nothing of it is written to disk; only inputs/outputs are saved.
         -> rotation_ref.npz, sampler_ref.npz
+  * nets/network.py `FaceRecNet.set_constraints` (204-218): the definition is executed the same way with its three
+    tf calls bound to numpy fp32 equivalents (see gen_set_constraints)
+        -> set_constraints_ref.npz
   * the native rasterisers need TensorFlow / OpenCV / MEX headers and are not buildable here; their known
     answers K1-K6 were recorded by the survey's probe of the verbatim-compiled functor and are
     transcribed in kat_survey.json (hand-written data, not generated here).
@@ -75,6 +78,51 @@ def gen_sampler():
                         **out)
 
 
+def gen_set_constraints():
+    """FaceRecNet.set_constraints (nets/network.py:204-218) is TensorFlow graph code: three tf calls (nn.sigmoid, concat,
+    expand_dims) around plain slicing and scaling.  The function definition is pulled out of the parsed AST and executed
+    with those three names bound to their numpy fp32 equivalents, so the reference's OWN slice boundaries, scale factors
+    and concatenation order produce the fixture; what is NOT the reference's is the sigmoid's last bits (TF 1.2's kernel
+    cannot be observed here: sigmoid = 1 / (1 + exp(-x)) evaluated in fp32 by numpy) -- stated in the provenance."""
+    code = _extract_functions(os.path.join(REF, "nets/network.py"), ["set_constraints"], cls="FaceRecNet")
+
+    class _NN:
+        @staticmethod
+        def sigmoid(x):
+            x = np.asarray(x, np.float32)
+            with np.errstate(over="ignore"):
+                return (np.float32(1.0) / (np.float32(1.0) + np.exp(-x))).astype(np.float32)
+
+    class _TF:
+        nn = _NN
+
+        @staticmethod
+        def concat(parts, axis):
+            return np.concatenate(parts, axis=axis)
+
+        @staticmethod
+        def expand_dims(x, axis):
+            return np.expand_dims(x, axis)
+
+    ns = {"tf": _TF, "np": np}
+    exec(code, ns)
+    out = {}
+    for tag, (ns_, ne_, im, B, seed) in {"a": (199, 29, 200, 6, 1), "b": (9, 5, 40, 3, 2), "c": (199, 29, 448, 2, 3)}.items():
+        net = ns["FaceRecNet"]()
+        net.im_size, net.ndim_pose, net.ndim_shape, net.ndim = im, 7, ns_, 7 + ns_ + ne_
+        rs = np.random.RandomState(seed)
+        raw = (rs.standard_normal((B, 1, 1, net.ndim)) * rs.choice([0.1, 1.0, 5.0, 30.0], (B, 1, 1, net.ndim))).astype(np.float32)
+        raw[0, 0, 0, :4] = [0.0, -120.0, 120.0, -0.0]          # saturation: sigmoid -> 0 / 1 exactly
+        res = net.set_constraints(raw)
+        assert res.dtype == np.float32 and res.shape == raw.shape
+        out["raw_" + tag], out["out_" + tag] = raw, res
+        out["cfg_" + tag] = np.array([ns_, ne_, im], np.int64)
+    np.savez_compressed(os.path.join(HERE, "set_constraints_ref.npz"),
+                        provenance="reference nets/network.py:204-218 executed in the build container with tf.nn.sigmoid / "
+                                   "tf.concat / tf.expand_dims bound to numpy fp32 equivalents (slicing, scale factors and "
+                                   "order are the reference's; the sigmoid's last bits are numpy's, TF being absent)", **out)
+
+
 def gen_oracle_pins():
     from oracle import oracle as O
     synth = importlib.import_module("3dfacerecon_amd.utils.synth")
@@ -140,6 +188,7 @@ def gen_config1():
 if __name__ == "__main__":
     gen_rotation()
     gen_sampler()
+    gen_set_constraints()
     gen_oracle_pins()
     gen_config1()
     for f in sorted(os.listdir(HERE)):

@@ -76,3 +76,21 @@ def test_sampler_vs_reference_fixture(synth):
             ref = z[name + tag]
             assert ours.dtype == ref.dtype and ours.shape == ref.shape
             np.testing.assert_array_equal(ours, ref)
+
+
+def test_set_constraints_vs_reference_structure_fixture(oracle):
+    """oracle.set_constraints == the reference's own set_constraints body (nets/network.py:204-218) executed with numpy
+    standing in for its three tf calls (tests/golden/make_golden.py::gen_set_constraints), bit for bit."""
+    z = np.load(os.path.join(GOLDEN, "set_constraints_ref.npz"))
+    for tag in "abc":
+        n_shape, n_exp, im = (int(v) for v in z["cfg_" + tag])
+        got = oracle.set_constraints(z["raw_" + tag], im, 7, n_shape)
+        want = z["out_" + tag]
+        assert got.dtype == want.dtype and got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+        q = want.reshape(-1, 7 + n_shape + n_exp)
+        assert np.all(np.abs(q[:, 0:3]) <= 1.5) and np.all((q[:, 3:5] >= 0) & (q[:, 3:5] <= im))
+        assert np.all(q[:, 5] == 0) and np.all((q[:, 6] >= 0) & (q[:, 6] <= np.float32(1e-3)))
+        assert np.all((q[:, 7:7 + n_shape] >= 0) & (q[:, 7:7 + n_shape] <= 1e4)) and np.all(np.abs(q[:, 7 + n_shape:]) <= 1.5)
+    a = z["out_a"][0, 0, 0]
+    np.testing.assert_array_equal(a[:4], np.array([0.0, -1.5, 1.5, 100.0], np.float32))   # sigmoid(0, -120, 120, -0)
