@@ -402,8 +402,11 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
 #ifndef FR_PROBE_DECODE
 #define FR_PROBE_DECODE 0  // development probes (tools/decode_probe.hip): 1 = no MFMA, 2 = requests hit 256 tiles, 4 = no prologue, 8 = no A requests, 16 = no LDS B reads, 32 = (almost) no stores
 #endif
-#define FR_RING_LD(dst, sbase, voff) \
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase))
+#define FR_RING_LD(dst, sbase, voff)                                                                   \
+    {                                                                                                  \
+        if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase)); \
+        else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));       \
+    }
 
 template <int R>
 __device__ __forceinline__ void ring_wait(f32x4& slot) {
@@ -415,7 +418,8 @@ __device__ __forceinline__ void ring_wait(f32x4& slot) {
 // WPE: waves per SIMD the register allocation is sized for (>= DEC_WAVES / 4).  A workgroup of fewer waves than that
 // leaves VGPRs free on purpose: the 8-wave form (WPE = 4: <= 128 VGPRs, half the register file) lets the render
 // kernels of the previous batch share the CU with the decode of the next one (pipeline.py, PipelinedPlan).
-template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64, int WPE = DEC_WAVES / 4>
+// NT: the basis stream is requested with the non-temporal hint (read once per launch by one CU pair of waves).
+template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64, int WPE = DEC_WAVES / 4, bool NT = false>
 __global__ __launch_bounds__(DEC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void decode_ring_kernel(DecodeArgs a) {
     constexpr int DEC_BLOCK = DEC_WAVES * 64;
@@ -585,15 +589,15 @@ static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int cus, size_
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
-template <int GS, int GE, int R, int NBW, int WAVES, int MB = 64, int WPE = WAVES / 4>
+template <int GS, int GE, int R, int NBW, int WAVES, int MB = 64, int WPE = WAVES / 4, bool NT = false>
 static int launch_decode_ring(const fr::DecodeArgs& a, size_t lds, int cus, size_t tiles, hipStream_t stream) {
     static unsigned char lds_ok[64];
-    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE>), lds_ok) !=
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT>), lds_ok) !=
         hipSuccess)
         return FR_ERR_LAUNCH;
     const int slots = WAVES / a.halves;
     const int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
-    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
@@ -640,6 +644,8 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
         const int waves_env = getenv("FR_DECODE_WAVES") ? atoi(getenv("FR_DECODE_WAVES")) : 16;  // read per call (probe / PipelinedPlan knob)
         if (ring && nbw == 1) rc = launch_decode_ring<13, 2, 8, 1, 16>(a, lds, cus, tiles, stream);
         else if (ring && waves_env == 8) rc = launch_decode_ring<13, 2, 8, 2, 8, 64, 4>(a, lds, cus, tiles, stream);
+        else if (ring && getenv("FR_DECODE_NT") && atoi(getenv("FR_DECODE_NT")))
+            rc = launch_decode_ring<13, 2, 8, 2, 16, 64, 4, true>(a, lds, cus, tiles, stream);
         else if (ring) rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);
         else
             rc = nbw == 1   ? launch_decode_nbw<1, 16>(a, lds, cus, tiles, stream)

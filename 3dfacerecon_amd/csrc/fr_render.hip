@@ -57,6 +57,7 @@ struct RenderArgs {
     float* depth_img;      // [B,H,W,1] = max(depth, 1e-6)
     float wm1, hm1;        // (float)(W-1), (float)(H-1)
     uint32_t rows_magic;   // ceil(2^32 / rows): y / rows == umulhi(y, magic) for y, rows < 2^16
+    int nt_planes;         // experiment knob (FR_RESOLVE_NT): non-temporal stores for the output planes
     const int4* tri4;      // [ntri] pre-validated triangles {4*p1, 4*p2, 4*p3, valid} (pack_tri_kernel)
     uint32_t nseg_magic;   // ceil(2^32 / nseg): lid / nseg == umulhi(lid, magic) (launcher checks the range)
 };
@@ -80,6 +81,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 __device__ __forceinline__ void store3(float* p, float x, float y, float z) {
     *reinterpret_cast<f32x3u*>(p) = (f32x3u){x, y, z};
+}
+__device__ __forceinline__ void store3(float* p, float x, float y, float z, int nt) {
+    if (nt) __builtin_nontemporal_store((f32x3u){x, y, z}, reinterpret_cast<f32x3u*>(p));
+    else *reinterpret_cast<f32x3u*>(p) = (f32x3u){x, y, z};
+}
+__device__ __forceinline__ void store1(float* p, float x, int nt) {
+    if (nt) __builtin_nontemporal_store(x, p);
+    else *p = x;
 }
 
 // One triangle against one strip [r0, r1): the reference's per-triangle body (render_depth_op.cc:201-219, 263-316)
@@ -283,13 +292,13 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
             for (int u = 0; u < UNR; u++) {
                 const int i = i0 + u * BLOCK;
                 if (i < npix) {
-                    dep[i] = cov[u] ? f32_unord((uint32_t)(kk[u] >> 32)) : bg_depth();
-                    tin[i] = cov[u] ? (float)t[u] : -1.0f;
+                    store1(dep + i, cov[u] ? f32_unord((uint32_t)(kk[u] >> 32)) : bg_depth(), a.nt_planes);
+                    store1(tin + i, cov[u] ? (float)t[u] : -1.0f, a.nt_planes);
                     float* tp = txi + 3 * (size_t)i;
-                    store3(tp, cov[u] ? tv[u].x : 0.0f, cov[u] ? tv[u].y : 0.0f, cov[u] ? tv[u].z : 0.0f);
+                    store3(tp, cov[u] ? tv[u].x : 0.0f, cov[u] ? tv[u].y : 0.0f, cov[u] ? tv[u].z : 0.0f, a.nt_planes);
                     if (!cov[u]) {
                         float* np = nrm + 3 * (size_t)i;
-                        store3(np, 0.0f, 0.0f, 0.0f);
+                        store3(np, 0.0f, 0.0f, 0.0f, a.nt_planes);
                     }
                 }
             }
@@ -807,7 +816,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                                 const int bit = __ffs((int)won) - 1;
                                 won &= won - 1;
                                 float* np = nplane + NSTRIDE * (ptrdiff_t)(p0 + (bit >> 3) * W + (bit & 7));
-                                store3(np, nv.x, nv.y, nv.z);
+                                store3(np, nv.x, nv.y, nv.z, a.nt_planes);
                             }
                         }
                     }
@@ -864,14 +873,11 @@ struct BwdRenderArgs {
     int splits, range;        // owner workgroups per face, vertices per owner
 };
 
-__device__ __forceinline__ bool bwd_pixel(const BwdRenderArgs& a, const float* __restrict__ ti, int i, int& p1, int& p2,
-                                          int& p3) {
-    const int t = f2i_x86(ti[i]);
-    if (t < 0 || t >= a.ntri) return false;  // deviation 2: background pixels carry tri_ind = -1
-    p1 = f2i_x86(a.tri[t]);
-    p2 = f2i_x86(a.tri[(size_t)a.ntri + t]);
-    p3 = f2i_x86(a.tri[2 * (size_t)a.ntri + t]);
-    return (unsigned)p1 < (unsigned)a.nver && (unsigned)p2 < (unsigned)a.nver && (unsigned)p3 < (unsigned)a.nver;
+// the three vertex ids of pixel value `tv` (a float-stored triangle index, -1 on the background): false when the pixel
+// contributes nothing (deviation 2: tri_ind < 0; deviation 3: an id outside [0,nver))
+__device__ __forceinline__ int bwd_tri_of(float tv, int ntri) {
+    const int t = f2i_x86(tv);
+    return (t >= 0 && t < ntri) ? t : -1;
 }
 
 __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArgs a) {
@@ -885,18 +891,32 @@ __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArg
     const int sp = blockIdx.x - b * a.splits;
     const int v0 = sp * a.range;
     const int v1 = min(a.nver, v0 + a.range);
-    const float* __restrict__ g = a.depth_grad + (size_t)b * a.npix;
-    const float* __restrict__ ti = a.tri_ind + (size_t)b * a.npix;
+    const int npix = a.npix, ntri = a.ntri, nver = a.nver;
+    const float* __restrict__ g = a.depth_grad + (size_t)b * npix;
+    const float* __restrict__ ti = a.tri_ind + (size_t)b * npix;
+    const float* __restrict__ tri0 = a.tri;
+    const float* __restrict__ tri1 = a.tri + ntri;
+    const float* __restrict__ tri2 = a.tri + 2 * (size_t)ntri;
     for (int i = tid; i < v1 - v0; i += BWD_BLOCK) acc[i] = 0ull;
+    // four pixels per lane per trip (16-byte loads) when the face's planes are 16-byte aligned
+    const bool vec = ((npix & 3) == 0) && ((((uintptr_t)g | (uintptr_t)ti) & 15) == 0);
+    const int nq = vec ? (npix >> 2) : 0;
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(ti);
 
     // pass 1: the face's largest |c| over the covered pixels (max is order independent)
     uint32_t m = 0, bad = 0;
-    for (int i = tid; i < a.npix; i += BWD_BLOCK) {
-        const int t = f2i_x86(ti[i]);
-        if (t < 0 || t >= a.ntri) continue;
-        const float c = g[i] * 1.0f / 3.0f;
-        const uint32_t u = __float_as_uint(c) & 0x7FFFFFFFu;
-        if (u >= 0x7F800000u) bad = 1; else m = max(m, u);
+    {
+        auto see = [&](float gv, float tv) {
+            if (bwd_tri_of(tv, ntri) < 0) return;
+            const uint32_t u = __float_as_uint(gv * 1.0f / 3.0f) & 0x7FFFFFFFu;
+            if (u >= 0x7F800000u) bad = 1; else m = max(m, u);
+        };
+        for (int i = tid; i < nq; i += BWD_BLOCK) {
+            const float4 gv = g4[i], tv = t4[i];
+            see(gv.x, tv.x); see(gv.y, tv.y); see(gv.z, tv.z); see(gv.w, tv.w);
+        }
+        for (int i = 4 * nq + tid; i < npix; i += BWD_BLOCK) see(g[i], ti[i]);
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -909,48 +929,68 @@ __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArg
 #pragma unroll
     for (int w = 0; w < BWD_BLOCK / 64; w++) { m = max(m, wmax[w]); bad |= wbad[w]; }
 
-    float* gx = a.vertex_grad + (size_t)b * 3 * a.nver;
-    float* gy = gx + a.nver;
-    float* gz = gy + a.nver;
-    if (bad) {  // Inf / NaN gradients: fp32 LDS atomics
-        float* facc = reinterpret_cast<float*>(acc);
-        __syncthreads();
-        for (int i = tid; i < v1 - v0; i += BWD_BLOCK) facc[i] = 0.0f;
-        __syncthreads();
-        for (int i = tid; i < a.npix; i += BWD_BLOCK) {
-            int p[3];
-            if (!bwd_pixel(a, ti, i, p[0], p[1], p[2])) continue;
-            const float c = g[i] * 1.0f / 3.0f;
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                if (p[k] >= v0 && p[k] < v1) atomicAdd(&facc[p[k] - v0], c);
-        }
-        __syncthreads();
-        for (int i = tid; i < v1 - v0; i += BWD_BLOCK) { gx[v0 + i] = 0.0f; gy[v0 + i] = 0.0f; gz[v0 + i] = facc[i]; }
-        return;
-    }
+    float* gx = a.vertex_grad + (size_t)b * 3 * nver;
+    float* gy = gx + nver;
+    float* gz = gy + nver;
     // scale 2^k: the largest term lands in [2^40, 2^41); up to 2^21 terms (3 per pixel) stay below 2^62
     const int e = (int)(m >> 23) - 127;  // floor(log2 max|c|) for a normal float; -127 for subnormals / zero
     const double scale = ldexp(1.0, 40 - e);
     const double inv_scale = ldexp(1.0, e - 40);
-    if (m != 0) {
-        for (int i = tid; i < a.npix; i += BWD_BLOCK) {
-            int p[3];
-            if (!bwd_pixel(a, ti, i, p[0], p[1], p[2])) continue;
-            const float c = g[i] * 1.0f / 3.0f;
-            const long long q = __double2ll_rn((double)c * scale);  // exact product, one rounding to the 2^-k grid
-            if (q == 0) continue;
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                if (p[k] >= v0 && p[k] < v1) atomicAdd(&acc[p[k] - v0], (unsigned long long)q);
+    float* facc = reinterpret_cast<float*>(acc);  // Inf / NaN gradients: fp32 LDS atomics in the same buffer
+    if (bad) {
+        __syncthreads();
+        for (int i = tid; i < v1 - v0; i += BWD_BLOCK) facc[i] = 0.0f;
+        __syncthreads();
+    }
+    // one contribution: c = (g * 1.0f) / 3.0f to the three vertices of triangle t that this workgroup owns
+    auto add = [&](float gv, float f1, float f2, float f3) {
+        const int p1 = f2i_x86(f1), p2 = f2i_x86(f2), p3 = f2i_x86(f3);
+        if ((unsigned)p1 >= (unsigned)nver || (unsigned)p2 >= (unsigned)nver || (unsigned)p3 >= (unsigned)nver) return;
+        const float c = gv * 1.0f / 3.0f;
+        if (bad) {
+            if (p1 >= v0 && p1 < v1) atomicAdd(&facc[p1 - v0], c);
+            if (p2 >= v0 && p2 < v1) atomicAdd(&facc[p2 - v0], c);
+            if (p3 >= v0 && p3 < v1) atomicAdd(&facc[p3 - v0], c);
+        } else {
+            const unsigned long long q = (unsigned long long)__double2ll_rn((double)c * scale);  // exact product, one rounding
+            if (q == 0ull) return;
+            if (p1 >= v0 && p1 < v1) atomicAdd(&acc[p1 - v0], q);
+            if (p2 >= v0 && p2 < v1) atomicAdd(&acc[p2 - v0], q);
+            if (p3 >= v0 && p3 < v1) atomicAdd(&acc[p3 - v0], q);
+        }
+    };
+    if (m != 0 || bad) {
+        // pass 2, software pipelined: the (gradient, tri_ind) quad of the NEXT trip is requested before the twelve id
+        // gathers of the current one are consumed, so a trip costs one memory round trip instead of two
+        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), tv = make_float4(-1.f, -1.f, -1.f, -1.f);
+        if (tid < nq) { gv = g4[tid]; tv = t4[tid]; }
+        for (int i = tid; i < nq; i += BWD_BLOCK) {
+            const int t0 = bwd_tri_of(tv.x, ntri), t1 = bwd_tri_of(tv.y, ntri), t2 = bwd_tri_of(tv.z, ntri),
+                      t3 = bwd_tri_of(tv.w, ntri);
+            const int u0 = max(t0, 0), u1 = max(t1, 0), u2 = max(t2, 0), u3 = max(t3, 0);
+            const float a0 = tri0[u0], b0 = tri1[u0], c0 = tri2[u0];
+            const float a1 = tri0[u1], b1 = tri1[u1], c1 = tri2[u1];
+            const float a2 = tri0[u2], b2 = tri1[u2], c2 = tri2[u2];
+            const float a3 = tri0[u3], b3 = tri1[u3], c3 = tri2[u3];
+            const float4 gc = gv;
+            const int in = i + BWD_BLOCK;
+            if (in < nq) { gv = g4[in]; tv = t4[in]; }
+            if (t0 >= 0) add(gc.x, a0, b0, c0);
+            if (t1 >= 0) add(gc.y, a1, b1, c1);
+            if (t2 >= 0) add(gc.z, a2, b2, c2);
+            if (t3 >= 0) add(gc.w, a3, b3, c3);
+        }
+        for (int i = 4 * nq + tid; i < npix; i += BWD_BLOCK) {
+            const int t = bwd_tri_of(ti[i], ntri);
+            if (t >= 0) add(g[i], tri0[t], tri1[t], tri2[t]);
         }
     }
     __syncthreads();
     for (int i = tid; i < v1 - v0; i += BWD_BLOCK) {
         gx[v0 + i] = 0.0f;
         gy[v0 + i] = 0.0f;
-        // one rounding to 24 bits (int64 -> fp32), then an exact power-of-two scaling in double
-        gz[v0 + i] = (float)((double)(float)(long long)acc[i] * inv_scale);
+        // fixed point: one rounding to 24 bits (int64 -> fp32), then an exact power-of-two scaling in double
+        gz[v0 + i] = bad ? facc[i] : (float)((double)(float)(long long)acc[i] * inv_scale);
     }
 }
 
@@ -1104,6 +1144,7 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     a.im_gray = im_gray; a.net_in = net_in; a.depth_img = depth_img;
     a.wm1 = (float)(W - 1);
     a.hm1 = (float)(H - 1);
+    a.nt_planes = env_int("FR_RESOLVE_NT", 0);
     a.rows_magic = g.rows > 1 ? (uint32_t)((0x100000000ull + (unsigned)g.rows - 1) / (unsigned)g.rows) : 0u;
 
     const bool binned = g.binned_ok && ntri > 0 && !env_is("FR_RENDER_IMPL", "scan");

@@ -54,12 +54,10 @@ def _all_gather_batch(t):
     return torch.cat(parts, dim=-1)
 
 
-def get_spherical_harmonics_model(face_net, vertices_proj, im_gray, gather=False):
-    """Recovered intensity (B,H,W,1) of the first-order spherical-harmonics shading model (network.py:420-462)."""
-    fn = face_net
-    if fn.mu_tex is None or fn.pc_tex is None or fn.param_tex is None:
-        raise ValueError("the asset dict has no texture model (mu_tex / pc_tex / param_tex)")
-    abedo_image, normal_map = fn.compute_abedo_image(vertices_proj, fn.tri, fn.mu_tex)   # (B,H,W,1), (B,H,W,3)
+def spherical_harmonics_intensity(abedo_image, normal_map, im_gray, abedo_image_new, normal_map_new, gather=False):
+    """The linear-algebra core of get_spherical_harmonics_model (network.py:424-460) on already rendered maps:
+    per pixel, lighting l = (Y Y^T)^+ Y (I / (albedo + 1))^T over the batch (Y = [3 x B] normals), then the recovered
+    intensity albedo_new * (l^T Y_new).  All inputs [B,H,W,c]; returns [B,H,W,1]."""
     abedo = abedo_image.permute(1, 2, 3, 0)            # (H,W,1,B)
     Yz0 = normal_map.permute(1, 2, 3, 0)               # (H,W,3,B)
     I = im_gray.permute(1, 2, 3, 0)                    # (H,W,1,B)
@@ -67,11 +65,28 @@ def get_spherical_harmonics_model(face_net, vertices_proj, im_gray, gather=False
     Yl, rl = (Yz0, rhs) if not gather else (_all_gather_batch(Yz0), _all_gather_batch(rhs))
     Yz0_nec_inv = _pinv_sym3(Yl @ Yl.transpose(-1, -2))                                   # (H,W,3,3)
     lighting_lse = (Yz0_nec_inv @ Yl) @ rl.transpose(-1, -2)                               # (H,W,3,1)
+    Yz = normal_map_new.permute(1, 2, 3, 0)
+    intensity = abedo_image_new.permute(1, 2, 3, 0) * (lighting_lse.transpose(-1, -2) @ Yz)  # Eqn (8), (H,W,1,B)
+    return intensity.permute(3, 0, 1, 2)
+
+
+def get_spherical_harmonics_model(face_net, vertices_proj, im_gray, gather=False):
+    """Recovered intensity (B,H,W,1) of the first-order spherical-harmonics shading model (network.py:420-462): two
+    more render_depth calls (mean albedo, then mean + pc_tex . param_tex) feed spherical_harmonics_intensity."""
+    fn = face_net
+    if fn.mu_tex is None or fn.pc_tex is None or fn.param_tex is None:
+        raise ValueError("the asset dict has no texture model (mu_tex / pc_tex / param_tex)")
+    abedo_image, normal_map = fn.compute_abedo_image(vertices_proj, fn.tri, fn.mu_tex)   # (B,H,W,1), (B,H,W,3)
     texture_new = fn.mu_tex + (fn.pc_tex @ fn.param_tex).reshape(3, -1)                    # network.py:446-448
     abedo_new, normal_new = fn.compute_abedo_image(vertices_proj, fn.tri, texture_new)
-    Yz = normal_new.permute(1, 2, 3, 0)
-    intensity = abedo_new.permute(1, 2, 3, 0) * (lighting_lse.transpose(-1, -2) @ Yz)      # Eqn (8), (H,W,1,B)
-    return intensity.permute(3, 0, 1, 2)
+    return spherical_harmonics_intensity(abedo_image, normal_map, im_gray, abedo_new, normal_new, gather=gather)
+
+
+def combine_losses(losses):
+    """total = 1e-3 pose + 1e-6 geometry + 1e-3 SfS + 100 fidelity + 1e-5 smoothness (network.py:27-31, 373)"""
+    return (LAMBDA_POSE * losses['pose_loss'] + LAMBDA_GEO * losses['geometry_loss'] +
+            LAMBDA_SH * losses['spherical_harmonics_loss'] + LAMBDA_F * losses['fidelity_loss'] +
+            LAMBDA_SM * losses['smoothness_loss'])
 
 
 def get_loss(face_net, pred_params, params_label, im_gray, vertices_proj, coarse_depth_map, pred_depth_map,
@@ -92,7 +107,5 @@ def get_loss(face_net, pred_params, params_label, im_gray, vertices_proj, coarse
     losses['fidelity_loss'] = F.mse_loss(pred_depth_map, coarse_depth_map)
     filtered_depth = laplace_transform(pred_depth_map[..., 0])
     losses['smoothness_loss'] = filtered_depth.abs().sum()    # tf.contrib.layers.l1_regularizer(1.0), network.py:367
-    losses['total_loss'] = (LAMBDA_POSE * losses['pose_loss'] + LAMBDA_GEO * losses['geometry_loss'] +
-                            LAMBDA_SH * losses['spherical_harmonics_loss'] + LAMBDA_F * losses['fidelity_loss'] +
-                            LAMBDA_SM * losses['smoothness_loss'])
+    losses['total_loss'] = combine_losses(losses)
     return losses

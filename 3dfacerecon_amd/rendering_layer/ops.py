@@ -102,6 +102,7 @@ class _RenderDepth(torch.autograd.Function):
         h.check(rc, "fr_render_depth_forward")
         ctx.save_for_backward(tri_c, tri_ind)
         ctx.dims = (B, nver, ntri, H, W)
+        ctx.set_materialize_grads(False)  # an unused depth output (the SfS renders, network.py:423, 454) costs no backward
         return depth, tex_img, normal, tri_ind
 
     @staticmethod
@@ -111,9 +112,9 @@ class _RenderDepth(torch.autograd.Function):
         tri_c, tri_ind = ctx.saved_tensors
         B, nver, ntri, H, W = ctx.dims
         dev = tri_c.device
+        if depth_grad is None:   # nothing downstream used `depth`: the vertices get no gradient (reference ops.py:95)
+            return None, None, None, None
         vertex_grad = torch.empty((B, 3, nver), dtype=torch.float32, device=dev)
-        if depth_grad is None:
-            return vertex_grad.zero_(), None, None, None
         g = h.require_gpu_f32(depth_grad, "depth_grad")
         with torch.cuda.device(dev):
             rc = h.lib().fr_render_depth_backward(h.ptr(g), h.ptr(tri_c), h.ptr(tri_ind), h.ptr(vertex_grad), B, nver,

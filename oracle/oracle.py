@@ -269,3 +269,26 @@ def set_constraints(pred_params, im_size, ndim_pose=7, ndim_shape=199):
     out[..., ndim_pose:ps] = s[..., ndim_pose:ps] * np.float32(1e4)
     out[..., ps:] = s[..., ps:] * np.float32(3.0) - np.float32(1.5)
     return out
+
+
+def decode_3dmm_blas(params, mu, pc_shape, pc_exp, im_size, R=None):
+    """numpy transcription of FaceRecNet.vertices_transform (nets/network.py:140-171) the way the reference's graph
+    evaluates it: two dense fp32 matmuls through BLAS ([3N x ns] . [ns x B], [3N x ne] . [ne x B]), then the pose
+    product and the y flip.  Its summation order is BLAS's, not the written spec's, so it is NOT the parity oracle
+    (decode_3dmm is): it exists as the realistic CPU-baseline timing of the decode (bench.py cpu_baseline) and is held
+    to the float64 evaluation by tolerance in tests/test_oracle_kat.py."""
+    P = np.asarray(params, np.float32)
+    mu = np.asarray(mu, np.float32).reshape(-1)
+    pc_shape = np.asarray(pc_shape, np.float32)
+    pc_exp = np.asarray(pc_exp, np.float32)
+    B, N = P.shape[0], mu.shape[0] // 3
+    ns, ne = pc_shape.shape[1], pc_exp.shape[1]
+    pose, alpha, beta = P[:, :7], P[:, 7:7 + ns], P[:, 7 + ns:7 + ns + ne]
+    Rm = rotation_matrix_batch(pose[:, :3]) if R is None else np.asarray(R, np.float32).reshape(B, 3, 3)
+    shapes = (pc_shape @ alpha.T).T.reshape(B, 3, N)          # network.py:153-154 (blocked rows: coordinate r // N)
+    exprs = (pc_exp @ beta.T).T.reshape(B, 3, N)              # :155-156
+    vertex = (mu.reshape(1, 3, N) + shapes) + exprs           # :157-159
+    M = pose[:, 6].reshape(B, 1, 1) * Rm                      # f (.) R, :163-165
+    proj = np.matmul(M, vertex) + pose[:, 3:6].reshape(B, 3, 1)   # :165
+    proj[:, 1] = (np.float32(im_size) - proj[:, 1]) - np.float32(1.0)   # :167-169
+    return proj.astype(np.float32)

@@ -86,9 +86,14 @@ def test_config3_full_size_train_step(oracle, full_assets, synth):
         scale = np.abs(want).max()
         assert scale > 0
         np.testing.assert_allclose(got[:, 2], want[:, 2], rtol=0, atol=2e-6 * max(scale, 1.0) + 1e-9)
-    P = cap["params"].detach().cpu().numpy()
+    # decode backward of the SAME upstream gradient, isolated (the graph's params.grad also holds the pose / geometry
+    # loss terms): 32 faces at full size through fr_decode_3dmm_backward, faces 0 and 31 against the float64 oracle
+    p2 = cap["params"].detach().clone().requires_grad_(True)
+    orig_vt(p2).backward(v.grad)
+    P = p2.detach().cpu().numpy()
     G = v.grad.detach().cpu().numpy()
-    gp = cap["params"].grad.detach().cpu().numpy().astype(np.float64)
+    gp = p2.grad.detach().cpu().numpy().astype(np.float64)
+    assert bool(torch.isfinite(cap["params"].grad).all())
     for b in (0, 31):
         want = oracle.decode_3dmm_backward_f64(G[b:b + 1], P[b:b + 1], A["mu"], A["pc_shape"], A["pc_exp"])
         ns = A["ndim_shape"]

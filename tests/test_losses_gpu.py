@@ -1,0 +1,72 @@
+"""GPU: the objective's hot-path terms -- the geometry loss's basis product on the MFMA decode kernel and the whole
+get_loss on rendered maps -- against the numpy restatement (oracle/losses_np.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import losses_np as LN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_geometry_product_on_the_decode_kernel(full_assets):
+    A = full_assets
+    net = pkg("nets.network").FaceRecNet(mesh_data=A, batch_size=5, im_size=200)
+    rs = np.random.RandomState(0)
+    d = np.concatenate([rs.uniform(-1e4, 1e4, (5, 199)), rs.uniform(-3, 3, (5, 29))], 1).astype(np.float32)
+    x = torch.as_tensor(d, device="cuda:0").requires_grad_(True)
+    g = net.geometry_product(x)
+    assert tuple(g.shape) == (5, 3, 53215)
+    basis = np.concatenate([A["pc_shape"], A["pc_exp"]], 1).astype(np.float64)
+    want = (basis @ d.astype(np.float64).T).T.reshape(5, 3, 53215)
+    want[:, 1] *= -1.0                                    # the kernel's y row is (1 - y) - 1
+    got = g.detach().cpu().numpy()
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-6 * scale + 1e-6
+    # geometry loss and its gradient (d/dx mean(g^2) = 2/(3N B) basis^T g)
+    loss = (g * g).mean()
+    loss.backward()
+    assert abs(float(loss) - float(np.mean(want ** 2))) <= 1e-5 * float(np.mean(want ** 2))
+    gw = 2.0 / want.size * (np.abs(1) * (basis.T @ (basis @ d.astype(np.float64).T))).T
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gw, rtol=2e-4, atol=1e-6 * np.abs(gw).max())
+
+
+def test_get_loss_vs_numpy(small_assets, synth):
+    netm, L = pkg("nets.network"), pkg("nets.losses")
+    A = small_assets
+    B, S = 4, 40
+    net = netm.FaceRecNet(mesh_data=A, batch_size=B, im_size=S)
+    rs = np.random.RandomState(3)
+    nd = net.ndim
+    P = np.zeros((B, nd), np.float32)
+    P[:, 0:3] = rs.uniform(-0.4, 0.4, (B, 3))
+    P[:, 3:5] = rs.uniform(17, 23, (B, 2))
+    P[:, 6] = rs.uniform(1.6e-4, 2.2e-4, B)
+    P[:, 7:] = np.concatenate([rs.uniform(0, 1e4, (B, A["ndim_shape"])), rs.uniform(-1.5, 1.5, (B, A["ndim_exp"]))], 1)
+    lab = P + rs.standard_normal(P.shape).astype(np.float32) * np.array([0.1] * 3 + [2, 2, 0, 1e-5] + [300.0] * (nd - 7),
+                                                                         np.float32)
+    dev = "cuda:0"
+    pred = torch.as_tensor(P, device=dev).requires_grad_(True)
+    im = torch.rand((B, S, S, 1), generator=torch.Generator().manual_seed(1)).to(dev)
+    V = net.vertices_transform(pred)
+    coarse = net.coarse_net_input(V, im_gray=im)[1]
+    fine = (coarse + 0.05 * torch.rand((B, S, S, 1), generator=torch.Generator().manual_seed(2)).to(dev)).detach()
+    fine.requires_grad_(True)
+    Ls = L.get_loss(net, pred, torch.as_tensor(lab, device=dev), im, V, coarse, fine)
+    # numpy side, fed with the SAME rendered maps
+    with torch.no_grad():
+        alb, nmap = net.compute_abedo_image(V, net.tri, net.mu_tex)
+        tex_new = net.mu_tex + (net.pc_tex @ net.param_tex).reshape(3, -1)
+        alb2, nmap2 = net.compute_abedo_image(V, net.tri, tex_new)
+    c = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    want = {"pose_loss": LN.pose_loss(P, lab), "geometry_loss": LN.geometry_loss(P, lab, A["pc_shape"], A["pc_exp"]),
+            "spherical_harmonics_loss": LN.mse(c(im), LN.spherical_harmonics_intensity(c(alb), c(nmap), c(im), c(alb2), c(nmap2))),
+            "fidelity_loss": LN.mse(c(coarse), c(fine)), "smoothness_loss": LN.smoothness_loss(c(fine))}
+    want["total_loss"] = LN.total_loss(want)
+    for k, w in want.items():
+        assert abs(float(Ls[k]) - w) <= 2e-3 * abs(w) + 1e-7, (k, float(Ls[k]), w)
+    assert float((c(alb) > 1e-6).mean()) > 0.1                              # the face is really rendered
+    Ls["total_loss"].backward()
+    assert bool(torch.isfinite(pred.grad).all()) and float(pred.grad[:, 7:].abs().max()) > 0
+    assert fine.grad is not None and float(fine.grad.abs().max()) > 0

@@ -62,3 +62,21 @@ def test_rotation_probe(oracle):
 
 def test_background_constant(oracle):
     assert float(oracle.BG_DEPTH) == -100000000376832.0
+
+
+def test_blas_decode_baseline_tracks_the_float64_formula(oracle, small_assets):
+    """decode_3dmm_blas (the cpu_baseline's matmul-style decode) is the same formula as the parity oracle: both sit
+    within a few fp32 ulp of the float64 evaluation (different summation orders, so not bit-equal to each other)."""
+    A = small_assets
+    rs = np.random.RandomState(0)
+    B = 5
+    P = np.zeros((B, 7 + A["ndim_shape"] + A["ndim_exp"]), np.float32)
+    P[:, 0:3] = rs.uniform(-1, 1, (B, 3))
+    P[:, 3:5] = rs.uniform(15, 25, (B, 2))
+    P[:, 6] = rs.uniform(1.5e-4, 2.5e-4, B)
+    P[:, 7:] = np.concatenate([rs.uniform(0, 1e4, (B, A["ndim_shape"])), rs.uniform(-1.5, 1.5, (B, A["ndim_exp"]))], 1)
+    v64 = oracle.decode_3dmm_f64(P, A["mu"], A["pc_shape"], A["pc_exp"], 40.0)
+    for v in (oracle.decode_3dmm_blas(P, A["mu"], A["pc_shape"], A["pc_exp"], 40.0),
+              oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 40.0)):
+        assert v.shape == v64.shape and v.dtype == np.float32
+        assert np.abs(v - v64).max() <= 8 * np.spacing(np.float32(np.abs(v64).max()))
