@@ -644,9 +644,13 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
         const int waves_env = getenv("FR_DECODE_WAVES") ? atoi(getenv("FR_DECODE_WAVES")) : 16;  // read per call (probe / PipelinedPlan knob)
         if (ring && nbw == 1) rc = launch_decode_ring<13, 2, 8, 1, 16>(a, lds, cus, tiles, stream);
         else if (ring && waves_env == 8) rc = launch_decode_ring<13, 2, 8, 2, 8, 64, 4>(a, lds, cus, tiles, stream);
-        else if (ring && getenv("FR_DECODE_NT") && atoi(getenv("FR_DECODE_NT")))
+        else if (ring && getenv("FR_DECODE_NT") && !atoi(getenv("FR_DECODE_NT")))
+            rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);  // A/B knob: default-policy basis loads
+        else if (ring)
+            // the basis stream carries the non-temporal hint: it is read once per launch, and keeping its 153 MB out of
+            // the way leaves the L2 / Infinity Cache to the vertices and hit records the render kernels re-read (measured
+            // in the pipeline: decode +2 us, emit -1.5 us, resolve -5 us per 64-face step)
             rc = launch_decode_ring<13, 2, 8, 2, 16, 64, 4, true>(a, lds, cus, tiles, stream);
-        else if (ring) rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);
         else
             rc = nbw == 1   ? launch_decode_nbw<1, 16>(a, lds, cus, tiles, stream)
                  : nbw == 2 ? launch_decode_nbw<2, 16>(a, lds, cus, tiles, stream)

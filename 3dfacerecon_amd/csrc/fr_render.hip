@@ -57,7 +57,6 @@ struct RenderArgs {
     float* depth_img;      // [B,H,W,1] = max(depth, 1e-6)
     float wm1, hm1;        // (float)(W-1), (float)(H-1)
     uint32_t rows_magic;   // ceil(2^32 / rows): y / rows == umulhi(y, magic) for y, rows < 2^16
-    int nt_planes;         // experiment knob (FR_RESOLVE_NT): non-temporal stores for the output planes
     const int4* tri4;      // [ntri] pre-validated triangles {4*p1, 4*p2, 4*p3, valid} (pack_tri_kernel)
     uint32_t nseg_magic;   // ceil(2^32 / nseg): lid / nseg == umulhi(lid, magic) (launcher checks the range)
 };
@@ -82,14 +81,7 @@ typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 __device__ __forceinline__ void store3(float* p, float x, float y, float z) {
     *reinterpret_cast<f32x3u*>(p) = (f32x3u){x, y, z};
 }
-__device__ __forceinline__ void store3(float* p, float x, float y, float z, int nt) {
-    if (nt) __builtin_nontemporal_store((f32x3u){x, y, z}, reinterpret_cast<f32x3u*>(p));
-    else *reinterpret_cast<f32x3u*>(p) = (f32x3u){x, y, z};
-}
-__device__ __forceinline__ void store1(float* p, float x, int nt) {
-    if (nt) __builtin_nontemporal_store(x, p);
-    else *p = x;
-}
+
 
 // One triangle against one strip [r0, r1): the reference's per-triangle body (render_depth_op.cc:201-219, 263-316)
 // with the depth test replaced by the packed-key LDS max.
@@ -292,13 +284,13 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
             for (int u = 0; u < UNR; u++) {
                 const int i = i0 + u * BLOCK;
                 if (i < npix) {
-                    store1(dep + i, cov[u] ? f32_unord((uint32_t)(kk[u] >> 32)) : bg_depth(), a.nt_planes);
-                    store1(tin + i, cov[u] ? (float)t[u] : -1.0f, a.nt_planes);
+                    dep[i] = cov[u] ? f32_unord((uint32_t)(kk[u] >> 32)) : bg_depth();
+                    tin[i] = cov[u] ? (float)t[u] : -1.0f;
                     float* tp = txi + 3 * (size_t)i;
-                    store3(tp, cov[u] ? tv[u].x : 0.0f, cov[u] ? tv[u].y : 0.0f, cov[u] ? tv[u].z : 0.0f, a.nt_planes);
+                    store3(tp, cov[u] ? tv[u].x : 0.0f, cov[u] ? tv[u].y : 0.0f, cov[u] ? tv[u].z : 0.0f);
                     if (!cov[u]) {
                         float* np = nrm + 3 * (size_t)i;
-                        store3(np, 0.0f, 0.0f, 0.0f, a.nt_planes);
+                        store3(np, 0.0f, 0.0f, 0.0f);
                     }
                 }
             }
@@ -707,7 +699,10 @@ __device__ __forceinline__ uint32_t window_rows_below(int n) {
     return n >= SMALL_H ? 0xFFFFFFFFu : (n <= 0 ? 0u : (1u << (8 * n)) - 1u);
 }
 
-constexpr size_t resolve_scratch_bytes(int block) { return 2 * (size_t)(block + 1) * 4 + (size_t)block * 2 + 64 * 4 + 16; }
+constexpr int SLOT_CAP = 3072;  // flattened record list of a bin kept in LDS (12 KiB); longer lists fall back to a search
+constexpr size_t resolve_scratch_bytes(int block) {
+    return 2 * (size_t)(block + 1) * 4 + (size_t)block * 2 + 64 * 4 + 16 + (size_t)SLOT_CAP * 4;
+}
 
 // The bin's records are spread over the face's segments (a few per segment).  Walking segments one after the other
 // would serialise ~4 dependent memory round trips per segment; instead the per-segment counts are prefix-summed in
@@ -728,6 +723,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     uint32_t* prefb = pref + BLOCK + 1;                                         // [BLOCK+1] big-record list offsets
     uint16_t* lo16 = reinterpret_cast<uint16_t*>(prefb + BLOCK + 1);           // [BLOCK]
     uint32_t* wtot = reinterpret_cast<uint32_t*>(lo16 + BLOCK);                 // [64] (BLOCK even: 4-byte aligned)
+    uint32_t* slotlist = wtot + 64;                                             // [SLOT_CAP] record slot of list entry j
     const unsigned long long KBG = bg_key();
     for (int i = tid; i < npix; i += BLOCK) keys[i] = KBG;
     const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.nver;
@@ -767,10 +763,16 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                     pref[BLOCK] = tot_s;
                     prefb[BLOCK] = tot_b;
                 }
+                // the flattened list itself: segment `seg` owns entries [ex_s, ex_s + hi - lo) -- a handful each -- and
+                // writes their record slots, so that both passes find record j with ONE LDS read instead of a
+                // log2(BLOCK)-step search through the prefix sums
+                if (tot_s <= (uint32_t)SLOT_CAP)
+                    for (uint32_t i = 0; i < hi - lo; i++) slotlist[ex_s + i] = (uint32_t)tid * SEG + lo + i;
                 __syncthreads();  // also orders the key initialisation before the first atomics
             }
             // ---- this strip's small records (own bucket + the two boundary buckets) ----
             const uint32_t total = pref[BLOCK];
+            const bool listed = total <= (uint32_t)SLOT_CAP;
             for (uint32_t j0 = tid; j0 < total; j0 += BLOCK * RU) {
                 uint4 r[RU];
                 uint32_t slot[RU];
@@ -780,11 +782,15 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                     r[u] = make_uint4(0, 0, 0, 0);
                     slot[u] = 0;
                     if (j < total) {
-                        int k = 0;
+                        if (listed) {
+                            slot[u] = slotlist[j];
+                        } else {
+                            int k = 0;
 #pragma unroll
-                        for (int step = BLOCK >> 1; step > 0; step >>= 1)
-                            if (pref[k + step] <= j) k += step;  // largest k with pref[k] <= j
-                        slot[u] = (uint32_t)k * SEG + lo16[k] + (j - pref[k]);
+                            for (int step = BLOCK >> 1; step > 0; step >>= 1)
+                                if (pref[k + step] <= j) k += step;  // largest k with pref[k] <= j
+                            slot[u] = (uint32_t)k * SEG + lo16[k] + (j - pref[k]);
+                        }
                         r[u] = Rbase[slot[u]];
                     }
                 }
@@ -816,7 +822,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                                 const int bit = __ffs((int)won) - 1;
                                 won &= won - 1;
                                 float* np = nplane + NSTRIDE * (ptrdiff_t)(p0 + (bit >> 3) * W + (bit & 7));
-                                store3(np, nv.x, nv.y, nv.z, a.nt_planes);
+                                store3(np, nv.x, nv.y, nv.z);
                             }
                         }
                     }
@@ -1144,7 +1150,6 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     a.im_gray = im_gray; a.net_in = net_in; a.depth_img = depth_img;
     a.wm1 = (float)(W - 1);
     a.hm1 = (float)(H - 1);
-    a.nt_planes = env_int("FR_RESOLVE_NT", 0);
     a.rows_magic = g.rows > 1 ? (uint32_t)((0x100000000ull + (unsigned)g.rows - 1) / (unsigned)g.rows) : 0u;
 
     const bool binned = g.binned_ok && ntri > 0 && !env_is("FR_RENDER_IMPL", "scan");

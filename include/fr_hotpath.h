@@ -114,8 +114,13 @@ int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R
  *   grad_vertex_proj [B,3,N] = dL/d vertex_proj;  vertex_proj [B,3,N] = the forward output (used for d f);
  *   mu / pc_shape / pc_exp in the reference layouts (not the packed image);  grad_params [B, 7+n_shape+n_exp].
  * d alpha = pc_shape^T dv, d beta = pc_exp^T dv with dv = (f R)^T dq, dq = (g_x, -g_y, g_z); d t3d = sum_p dq;
- * d f = sum_p (q - t3d) . dq / f (0 when f == 0); the three angles get 0: in the reference R passes through tf.py_func
- * (network.py:150), which has no gradient.  Deterministic (fixed-order partial sums, no float atomics). */
+ * d f = sum_p (R v_p) . dq evaluated as sum_p (q - t3d) . dq / f, which needs no second pass over the basis; the three
+ * angles get 0: in the reference R passes through tf.py_func (network.py:150), which has no gradient.
+ * f == 0 (only reachable when set_constraints' sigmoid underflows, raw input < -103): every vertex projects onto t3d, the
+ * quotient form is 0/0 and d f is DEFINED as 0 here (the true value sum_p (R v_p) . dq would need the un-projected
+ * vertices, i.e. another basis pass); d alpha = d beta = 0 and d t3d are exact in that case.  Stated, tested
+ * (tests/test_decode_backward_gpu.py::test_zero_focal_column), not silent.
+ * Deterministic (fixed-order partial sums, no float atomics). */
 size_t fr_decode_backward_workspace_bytes(int B, int N, int n_shape, int n_exp);
 
 int fr_decode_3dmm_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,

@@ -76,3 +76,26 @@ def test_gradient_flows_from_depth_to_params(full_assets, synth):
     # d loss / d tz == number of covered pixels with depth > 1e-6 (each hands out 3 * 1/3)
     ncov = (depth > 1e-6).sum(dim=(1, 2, 3)).float()
     assert torch.allclose(g[:, 5], ncov, rtol=1e-4)
+
+
+def test_zero_focal_column(oracle, synth):
+    """f == 0 in one batch column (include/fr_hotpath.h): d f is defined as 0 there, d alpha = d beta = 0 (dv = f R^T dq
+    vanishes), d t3d = sum dq stays exact, and the other columns are untouched."""
+    A = synth.make_assets(9, 10, 12, 4, patch=None, seed_basis=19)
+    rs = np.random.RandomState(0)
+    P = _params(rs, 3, 12, 4)
+    P[1, 6] = 0.0
+    G = rs.standard_normal((3, 3, 90)).astype(np.float32)
+    net = net_mod().FaceRecNet(mesh_data=A, batch_size=3, im_size=200)
+    p = torch.as_tensor(P, device="cuda:0").requires_grad_(True)
+    net.vertices_transform(p).backward(torch.as_tensor(G, device="cuda:0"))
+    got = p.grad.cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(got))
+    assert got[1, 6] == 0.0 and np.all(got[1, 7:] == 0.0) and np.all(got[1, 0:3] == 0.0)
+    dq = G[1].astype(np.float64) * np.array([1.0, -1.0, 1.0])[:, None]
+    np.testing.assert_allclose(got[1, 3:6], dq.sum(1), rtol=1e-5, atol=1e-5)
+    keep = [0, 2]
+    want = oracle.decode_3dmm_backward_f64(G[keep], P[keep], A["mu"], A["pc_shape"], A["pc_exp"])
+    for sl in (slice(3, 6), slice(6, 7), slice(7, None)):
+        scale = np.abs(want[:, sl]).max() + 1e-30
+        assert np.abs(got[keep][:, sl] - want[:, sl]).max() / scale < 2e-5
