@@ -126,7 +126,10 @@ def main(argv=None):
     _save_png(os.path.join(args.out, 'test_abedoimg_hip_GPU.png'), abedo_map * 255.0)
     cov = float((tf_tri_ind >= 0).float().mean())
     print('Op time: {} s, Running time: {} s.  coverage {:.3f}'.format(t_graph, t_run, cov))
-    return {"coverage": cov, "loss": float(loss.detach()), "grad_abs_max": float(tf_vertex.grad.abs().max())}
+    # the loss reads the texture output only, which carries no vertex gradient (reference ops.py:95): autograd then
+    # hands the vertices no gradient at all
+    g = tf_vertex.grad
+    return {"coverage": cov, "loss": float(loss.detach()), "grad_abs_max": 0.0 if g is None else float(g.abs().max())}
 
 
 if __name__ == '__main__':
