@@ -129,29 +129,44 @@ __device__ __forceinline__ void mfma_step(float a, const typename BFrag<NBW>::ty
     for (int nb = 0; nb < NBW; nb++)
         acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bsel<NBW>(bq, nb), acc[nb], 0, 0, 0);
 }
-// Plg points at this lane's B fragment of the group's first k-step; consecutive k-steps are 64*NBW floats apart.
+// LDS image of the parameters (B operand): element (k, column j of 16, block nb) sits at k*16*NBW + pcol(k, j)*NBW + nb.
+// For NBW <= 2 the column is XOR-swizzled with the k index: the prologue stores the image with 16 consecutive k per
+// quarter-wave (stride 16*NBW floats = the same bank for every k un-swizzled: a 16-way conflict on every ds_write,
+// PMC: 1.85 M conflict cycles per launch), swizzled they spread over 16 banks; a k-step's fragment read stays one
+// conflict-free ds_read (the 16 lanes of a k row read a permutation of the row).
 template <int NBW>
-__device__ __forceinline__ typename BFrag<NBW>::type ldb(const float* Plg, int j) {
-    return *reinterpret_cast<const typename BFrag<NBW>::type*>(Plg + (size_t)j * 64 * NBW);
+__device__ __forceinline__ int pcol(int k, int j) {
+    if constexpr (NBW <= 2) return j ^ (k & 15);
+    else return j;
+}
+// Plg points at the group's first k-step (wave-uniform base + hf); sw[j] is this lane's element offset for k-step j.
+template <int NBW>
+__device__ __forceinline__ typename BFrag<NBW>::type ldb(const float* Plg, const int (&sw)[4], int j) {
+    return *reinterpret_cast<const typename BFrag<NBW>::type*>(Plg + sw[j]);
 }
 template <int NBW>
-__device__ __forceinline__ void mfma_group3(float4 a0, float4 a1, float4 a2, const float* Plg, f32x4 (&acc0)[NBW],
-                                            f32x4 (&acc1)[NBW], f32x4 (&acc2)[NBW]) {
-    typename BFrag<NBW>::type bq = ldb<NBW>(Plg, 0);
+__device__ __forceinline__ void lane_swizzle(int lane, int (&sw)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) sw[j] = (j * 64 + (lane & 48) + pcol<NBW>(4 * j + (lane >> 4), lane & 15)) * NBW;
+}
+template <int NBW>
+__device__ __forceinline__ void mfma_group3(float4 a0, float4 a1, float4 a2, const float* Plg, const int (&sw)[4],
+                                            f32x4 (&acc0)[NBW], f32x4 (&acc1)[NBW], f32x4 (&acc2)[NBW]) {
+    typename BFrag<NBW>::type bq = ldb<NBW>(Plg, sw, 0);
     mfma_step<NBW>(a0.x, bq, acc0); mfma_step<NBW>(a1.x, bq, acc1); mfma_step<NBW>(a2.x, bq, acc2);
-    bq = ldb<NBW>(Plg, 1);
+    bq = ldb<NBW>(Plg, sw, 1);
     mfma_step<NBW>(a0.y, bq, acc0); mfma_step<NBW>(a1.y, bq, acc1); mfma_step<NBW>(a2.y, bq, acc2);
-    bq = ldb<NBW>(Plg, 2);
+    bq = ldb<NBW>(Plg, sw, 2);
     mfma_step<NBW>(a0.z, bq, acc0); mfma_step<NBW>(a1.z, bq, acc1); mfma_step<NBW>(a2.z, bq, acc2);
-    bq = ldb<NBW>(Plg, 3);
+    bq = ldb<NBW>(Plg, sw, 3);
     mfma_step<NBW>(a0.w, bq, acc0); mfma_step<NBW>(a1.w, bq, acc1); mfma_step<NBW>(a2.w, bq, acc2);
 }
 template <int NBW>
-__device__ __forceinline__ void mfma_group1(float4 a0, const float* Plg, f32x4 (&acc0)[NBW]) {
-    mfma_step<NBW>(a0.x, ldb<NBW>(Plg, 0), acc0);
-    mfma_step<NBW>(a0.y, ldb<NBW>(Plg, 1), acc0);
-    mfma_step<NBW>(a0.z, ldb<NBW>(Plg, 2), acc0);
-    mfma_step<NBW>(a0.w, ldb<NBW>(Plg, 3), acc0);
+__device__ __forceinline__ void mfma_group1(float4 a0, const float* Plg, const int (&sw)[4], f32x4 (&acc0)[NBW]) {
+    mfma_step<NBW>(a0.x, ldb<NBW>(Plg, sw, 0), acc0);
+    mfma_step<NBW>(a0.y, ldb<NBW>(Plg, sw, 1), acc0);
+    mfma_step<NBW>(a0.z, ldb<NBW>(Plg, sw, 2), acc0);
+    mfma_step<NBW>(a0.w, ldb<NBW>(Plg, sw, 3), acc0);
 }
 
 // Work distribution shared by the decode kernels.  A workgroup works on `slots` tiles at a time (slot = wave / halves).
@@ -197,7 +212,8 @@ __device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem
         const bool rowok = bb < nbatch;
         const float* prow = a.params + (size_t)(a.b0 + (rowok ? bb : 0)) * nd + FR_N_POSE;
         const int nbk = bb >> 4;
-        float* dst = smem + (size_t)(nbk / NBW) * half_floats + (size_t)(bb & 15) * NBW + (nbk % NBW);
+        float* dst = smem + (size_t)(nbk / NBW) * half_floats + (nbk % NBW);   // + k*16*NBW + pcol(k, bb & 15)*NBW
+        const int jb = bb & 15;
         const int KS = GS * KGROUP, KE = GE * KGROUP;
         if (a.ns > 0) {
             for (int k0 = sub; k0 < KS; k0 += 8 * TPR) {
@@ -207,7 +223,7 @@ __device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int k = k0 + TPR * u;
-                    if (k < KS) dst[(size_t)k * 16 * NBW] = (rowok && k < a.ns) ? v[u] : 0.f;
+                    if (k < KS) dst[(size_t)k * 16 * NBW + pcol<NBW>(k, jb) * NBW] = (rowok && k < a.ns) ? v[u] : 0.f;
                 }
             }
         }
@@ -219,7 +235,8 @@ __device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int k = k0 + TPR * u;
-                    if (k < KE) dst[(size_t)(KS + k) * 16 * NBW] = (rowok && k < a.ne) ? v[u] : 0.f;
+                    if (k < KE)
+                        dst[(size_t)(KS + k) * 16 * NBW + pcol<NBW>(KS + k, jb) * NBW] = (rowok && k < a.ne) ? v[u] : 0.f;
                 }
             }
         }
@@ -330,7 +347,9 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
     const TileWalk tw = tile_walk(slot, slots, (int)blockIdx.x, (int)gridDim.x);
     for (int tile = tw.first; tile < tiles; tile += tw.stride) {
         const float4* Ap = a.A + (size_t)tile * G * 3 * 64 + lane;   // group g, coordinate c at Ap[(g*3+c)*64]
-        const float* Pll = smem + (size_t)hf * half_floats + (size_t)lane * NBW;  // this lane's B fragment, k-step 0
+        const float* Pll = smem + (size_t)hf * half_floats;  // this half's parameter image; lane offsets in sw[]
+        int sw[4];
+        lane_swizzle<NBW>(lane, sw);
         f32x4 s0[NBW], s1[NBW], s2[NBW];
 #pragma unroll
         for (int nb = 0; nb < NBW; nb++) s0[nb] = s1[nb] = s2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -344,7 +363,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
             const int gn = g + 2 < G ? g + 2 : G - 1;  // the last S groups prefetch the first E groups
             const float4 n0 = Ap[(size_t)(gn * 3 + 0) * 64], n1 = Ap[(size_t)(gn * 3 + 1) * 64],
                          n2 = Ap[(size_t)(gn * 3 + 2) * 64];
-            mfma_group3<NBW>(c0, c1, c2, Pll + (size_t)g * 256 * NBW, s0, s1, s2);
+            mfma_group3<NBW>(c0, c1, c2, Pll + (size_t)g * 256 * NBW, sw, s0, s1, s2);
             c0 = d0; c1 = d1; c2 = d2;
             d0 = n0; d1 = n1; d2 = n2;
         }
@@ -367,19 +386,19 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
             f32x4 e[NBW];
 #pragma unroll
             for (int nb = 0; nb < NBW; nb++) e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (GE > 0) mfma_group1<NBW>(c0, Pll + (size_t)GS * 256 * NBW, e);
-            if (GE > 1) mfma_group1<NBW>(d0, Pll + (size_t)(GS + 1) * 256 * NBW, e);
-            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 0) * 64], Pll + (size_t)g * 256 * NBW, e);
+            if (GE > 0) mfma_group1<NBW>(c0, Pll + (size_t)GS * 256 * NBW, sw, e);
+            if (GE > 1) mfma_group1<NBW>(d0, Pll + (size_t)(GS + 1) * 256 * NBW, sw, e);
+            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 0) * 64], Pll + (size_t)g * 256 * NBW, sw, e);
 #pragma unroll
             for (int nb = 0; nb < NBW; nb++) { s0[nb] = s0[nb] + e[nb]; e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            if (GE > 0) mfma_group1<NBW>(c1, Pll + (size_t)GS * 256 * NBW, e);
-            if (GE > 1) mfma_group1<NBW>(d1, Pll + (size_t)(GS + 1) * 256 * NBW, e);
-            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 1) * 64], Pll + (size_t)g * 256 * NBW, e);
+            if (GE > 0) mfma_group1<NBW>(c1, Pll + (size_t)GS * 256 * NBW, sw, e);
+            if (GE > 1) mfma_group1<NBW>(d1, Pll + (size_t)(GS + 1) * 256 * NBW, sw, e);
+            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 1) * 64], Pll + (size_t)g * 256 * NBW, sw, e);
 #pragma unroll
             for (int nb = 0; nb < NBW; nb++) { s1[nb] = s1[nb] + e[nb]; e[nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            if (GE > 0) mfma_group1<NBW>(c2, Pll + (size_t)GS * 256 * NBW, e);
-            if (GE > 1) mfma_group1<NBW>(d2, Pll + (size_t)(GS + 1) * 256 * NBW, e);
-            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 2) * 64], Pll + (size_t)g * 256 * NBW, e);
+            if (GE > 0) mfma_group1<NBW>(c2, Pll + (size_t)GS * 256 * NBW, sw, e);
+            if (GE > 1) mfma_group1<NBW>(d2, Pll + (size_t)(GS + 1) * 256 * NBW, sw, e);
+            for (int g = GS + 2; g < G; g++) mfma_group1<NBW>(Ap[(size_t)(g * 3 + 2) * 64], Pll + (size_t)g * 256 * NBW, sw, e);
 #pragma unroll
             for (int nb = 0; nb < NBW; nb++) s2[nb] = s2[nb] + e[nb];
         }
@@ -444,7 +463,9 @@ void decode_ring_kernel(DecodeArgs a) {
     const int hf = wave - slot * H2;
     const TileWalk tw = tile_walk(slot, slots, (int)blockIdx.x, (int)gridDim.x);
     const int tile0 = tw.first, tstride = tw.stride;
-    const float* Pll = smem + (size_t)hf * half_floats + (size_t)lane * NBW;
+    const float* Pll = smem + (size_t)hf * half_floats;
+    int sw[4];
+    lane_swizzle<NBW>(lane, sw);
     const unsigned voffA = (unsigned)lane * 16u;         // this lane's 16 bytes of a 1 KiB A fragment
     const unsigned voffM = (unsigned)(lane >> 4) * 16u;  // this lane's 4 vertices of a 64-byte mu row
     const char* Ab = reinterpret_cast<const char*>(a.A);
@@ -497,7 +518,7 @@ void decode_ring_kernel(DecodeArgs a) {
                 if (cc == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if ((FR_PROBE_DECODE & 16) == 0 || (ct == tile0 && g == 0)) bq[j] = ldb<NBW>(Pll + (size_t)g * 256 * NBW, j);
+                        if ((FR_PROBE_DECODE & 16) == 0 || (ct == tile0 && g == 0)) bq[j] = ldb<NBW>(Pll + (size_t)g * 256 * NBW, sw, j);
                     if (g == GS) {  // S finished: park it, restart the fmaf chain from +0 for E
 #pragma unroll
                         for (int c2 = 0; c2 < 3; c2++)
@@ -634,15 +655,16 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
             continue;
         }
         const int nbt = (min(B - b0, MAXB) + 15) / 16;  // 16-column blocks in this pass (1..4)
-        static const int nbw_env = getenv("FR_DECODE_NBW") ? atoi(getenv("FR_DECODE_NBW")) : 0;
+        const int nbw_env = getenv("FR_DECODE_NBW") ? atoi(getenv("FR_DECODE_NBW")) : 0;  // A/B knob, read per call
         int nbw = nbt == 1 ? 1 : 2;                     // column blocks per work item
         if (nbw_env == 4 && nbt > 2) nbw = 4;
+        if (nbw_env == 1) nbw = 1;                      // quarter-tile items: 13,304 at B = 64 (12.99 per SIMD)
         a.halves = (nbt + nbw - 1) / nbw;
         // the model's own basis shape (199 + 29 coefficients = 13 + 2 groups) takes the fully unrolled ring schedule
         const bool ring = ring_shape && nbw <= 2;
         int rc;
         const int waves_env = getenv("FR_DECODE_WAVES") ? atoi(getenv("FR_DECODE_WAVES")) : 16;  // read per call (probe / PipelinedPlan knob)
-        if (ring && nbw == 1) rc = launch_decode_ring<13, 2, 8, 1, 16>(a, lds, cus, tiles, stream);
+        if (ring && nbw == 1) rc = launch_decode_ring<13, 2, 8, 1, 16, 64, 4, true>(a, lds, cus, tiles, stream);
         else if (ring && waves_env == 8) rc = launch_decode_ring<13, 2, 8, 2, 8, 64, 4>(a, lds, cus, tiles, stream);
         else if (ring && getenv("FR_DECODE_NT") && !atoi(getenv("FR_DECODE_NT")))
             rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);  // A/B knob: default-policy basis loads

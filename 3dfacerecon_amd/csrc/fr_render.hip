@@ -466,54 +466,23 @@ constexpr int EMIT_BLOCK = 256;
 constexpr int TPT = 2;                 // triangles per thread in phase A
 constexpr int EMIT_ACTIVE = SEG / TPT; // threads that own triangles in phase A (252 of 256)
 
-// MINW: waves per SIMD the register allocation is held to (8 = the 64-VGPR budget of full occupancy, at the price of a few
-// spills outside the hot loops; 1 = whatever the body needs).
-template <int MINW>
-__global__ __launch_bounds__(EMIT_BLOCK, MINW) void raster_emit_kernel(RenderArgs a) {
+__global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     __shared__ uint32_t cnt[OFF_STRIDE];  // per-bucket record count; turned into the bucket's start offset in phase C
     __shared__ unsigned long long qn2;  // survivors queued: low word = single-pixel ones (from slot 0 up), high word =
                                         // multi-pixel ones (from slot SEG-1 down)
     __shared__ float4 qa[SEG];   // phase A->B: x1 y1 x2 y2          phase B->C: the record
     __shared__ float4 qb[SEG];   // phase A->B: x3 y3 z1 z2          phase B->C: the record's normal
     __shared__ uint2 qd[SEG];    // .x: z3 (raw bits) in A->B, then bucket << 16 | pos (~0 = none) in B->C; .y: local index
-    int tid = threadIdx.x;
-    const int S = a.strips;
-    const int nver = a.nver, ntri = a.ntri;
-    // Persistent workgroups: a workgroup walks several (face, segment) items.  Phase A of an item is two DEPENDENT memory
-    // round trips (triangle table -> vertices); walking items lets the table entries of the NEXT item be requested as
-    // soon as the current item's gathers are issued (the registers are free by then), so in steady state an item pays
-    // one round trip.  Items are dealt XCD-aware: workgroups that share blockIdx % 8 share an XCD / L2 and sweep one
-    // contiguous eighth of the (face-major) item list together, so a face's vertices meet in one L2.
-    const int total = a.B * a.nseg;
-    const int xcd = (int)blockIdx.x & 7;
-    const int q8 = total >> 3, r8 = total & 7;
-    const int ibase = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;  // this XCD's share [ibase, ibase + icnt)
-    const int icnt = q8 + (xcd < r8 ? 1 : 0);
-    const int gx = ((int)gridDim.x + 7 - xcd) >> 3;  // workgroups carrying this XCD label
-    int4 e[TPT];  // table entries of the item about to be processed
-    auto request_tri = [&](int lid_, int4 (&dst)[TPT]) {
-        const int b_ = a.nseg_magic ? (int)__umulhi((uint32_t)lid_, a.nseg_magic) : lid_ / a.nseg;
-        const int seg_ = lid_ - b_ * a.nseg;
-#pragma unroll
-        for (int u = 0; u < TPT; u++) {
-            const int t = seg_ * SEG + u * EMIT_ACTIVE + tid;
-            // one unconditional 16-byte load (saddr + 32-bit offset form)
-            dst[u] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.tri4) + (size_t)((uint32_t)min(t, ntri - 1) << 4));
-        }
-    };
-    int it = (int)blockIdx.x >> 3;
-    if (it < icnt) request_tri(ibase + it, e);
-    for (; it < icnt; it += gx) {
-    // (the thread id is made opaque once per item: otherwise every tid-derived address / mask of the body is hoisted out
-    // of the item loop and held in registers across it, which costs the kernel its 8 waves per SIMD)
-    asm volatile("" : "+v"(tid));
-    const int lid = ibase + it;
+    const int tid = threadIdx.x;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = a.nseg_magic ? (int)__umulhi((uint32_t)lid, a.nseg_magic) : lid / a.nseg;  // lid / nseg
     const int seg = lid - b * a.nseg;
+    const int S = a.strips;
     if (tid < 2 * S) cnt[tid] = 0;
     if (tid == 0) qn2 = 0ull;
     __syncthreads();
 
+    const int nver = a.nver, ntri = a.ntri;
     const float* __restrict__ vx = a.vertex + (size_t)b * 3 * nver;
     const float* __restrict__ vy = vx + nver;
     const float* __restrict__ vz = vy + nver;
@@ -521,22 +490,23 @@ __global__ __launch_bounds__(EMIT_BLOCK, MINW) void raster_emit_kernel(RenderArg
     // ---------------- phase A: pre-validated ids, gathers, bbox reject ----------------
     {
         bool surv[TPT], single[TPT];
+        int4 e[TPT];
         float x1[TPT], x2[TPT], x3[TPT], y1[TPT], y2[TPT], y3[TPT], z1[TPT], z2[TPT], z3[TPT];
         bool valid[TPT];
-        int4 ec[TPT];  // this item's entries (`e` is re-requested for the next item after phase B)
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
             const int t = seg * SEG + u * EMIT_ACTIVE + tid;
-            ec[u] = e[u];
-            valid[u] = ((int)(tid < EMIT_ACTIVE) & (int)(t < ntri) & ec[u].w) != 0;
+            // one unconditional 16-byte load (saddr + 32-bit offset form); no short-circuit on .w, or the compiler
+            // splits the load and serialises the two halves
+            e[u] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.tri4) + (size_t)((uint32_t)min(t, ntri - 1) << 4));
+            valid[u] = ((int)(tid < EMIT_ACTIVE) & (int)(t < ntri) & e[u].w) != 0;
         }
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
-            x1[u] = ld_boff(vx, ec[u].x); x2[u] = ld_boff(vx, ec[u].y); x3[u] = ld_boff(vx, ec[u].z);
-            y1[u] = ld_boff(vy, ec[u].x); y2[u] = ld_boff(vy, ec[u].y); y3[u] = ld_boff(vy, ec[u].z);
-            z1[u] = ld_boff(vz, ec[u].x); z2[u] = ld_boff(vz, ec[u].y); z3[u] = ld_boff(vz, ec[u].z);
+            x1[u] = ld_boff(vx, e[u].x); x2[u] = ld_boff(vx, e[u].y); x3[u] = ld_boff(vx, e[u].z);
+            y1[u] = ld_boff(vy, e[u].x); y2[u] = ld_boff(vy, e[u].y); y3[u] = ld_boff(vy, e[u].z);
+            z1[u] = ld_boff(vz, e[u].x); z2[u] = ld_boff(vz, e[u].y); z3[u] = ld_boff(vz, e[u].z);
         }
-
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
             // bbox = ceil(min) .. floor(max) per axis and the whole-triangle reject of render_depth_op.cc:276-283, in the
@@ -555,7 +525,7 @@ __global__ __launch_bounds__(EMIT_BLOCK, MINW) void raster_emit_kernel(RenderArg
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const float* tj = a.texture + (size_t)j * nver;
-                    tm[j] = div3((ld_boff(tj, ec[u].x) + ld_boff(tj, ec[u].y)) + ld_boff(tj, ec[u].z));
+                    tm[j] = div3((ld_boff(tj, e[u].x) + ld_boff(tj, e[u].y)) + ld_boff(tj, e[u].z));
                 }
                 a.tritex_ws[seg * SEG + u * EMIT_ACTIVE + tid] = make_float4(tm[0], tm[1], tm[2], 0.0f);
             }
@@ -645,12 +615,12 @@ __global__ __launch_bounds__(EMIT_BLOCK, MINW) void raster_emit_kernel(RenderArg
                 nrm4 = make_float4((float)(ay * bz - az * by), (float)(az * bx - ax * bz), (float)(ax * by - ay * bx), 0.0f);
                 if (a.tex_stride) {  // every face has its own texture: mean per emitting (face, triangle)
                     const float* __restrict__ tex = a.texture + (size_t)b * a.tex_stride;
-                    const int4 et = a.tri4[t];  // valid: checked in phase A
+                    const int4 e = a.tri4[t];  // valid: checked in phase A
                     float tm[3];
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
                         const float* tj = tex + (size_t)j * nver;
-                        tm[j] = div3((ld_boff(tj, et.x) + ld_boff(tj, et.y)) + ld_boff(tj, et.z));
+                        tm[j] = div3((ld_boff(tj, e.x) + ld_boff(tj, e.y)) + ld_boff(tj, e.z));
                     }
                     a.tritex_ws[(size_t)b * ntri + t] = make_float4(tm[0], tm[1], tm[2], 0.0f);
                 }
@@ -666,41 +636,37 @@ __global__ __launch_bounds__(EMIT_BLOCK, MINW) void raster_emit_kernel(RenderArg
         }
         qd[sl].x = tag;
     }
-    // the next item's table entries travel through phase C and the two barriers around the item boundary (requested
-    // here rather than right after the gathers: held across phase B they would push the kernel past 64 VGPRs)
-    if (it + gx < icnt) request_tri(ibase + it + gx, e);
     __syncthreads();
     // ---------------- phase C: bucket offsets, records out ----------------
+    // Every wave scans the (at most 64) bucket counts for itself and keeps bucket k's start in lane k's register: a
+    // record's base is one cross-lane read, and no third barrier (nor a single-wave scan the other three wait for) is
+    // needed.  Wave 0 also publishes the bucket ends for the resolver.
     uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
-    if (tid < 64) {  // one wave scans the (at most 64) bucket counts
-        const int lane = tid;
-        const uint32_t c = (tid < 2 * S) ? cnt[tid] : 0u;
-        uint32_t inc = c;
+    const int lane = tid & 63;
+    const uint32_t c = (lane < 2 * S) ? cnt[lane] : 0u;
+    uint32_t inc = c;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t n = __shfl_up(inc, d);
-            if (lane >= d) inc += n;
-        }
-        if (tid < 2 * S) {
-            cnt[tid] = inc - c;          // start of bucket k
-            off[tid] = (uint16_t)inc;    // end of bucket k (off[0] = #big)
-        }
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n = __shfl_up(inc, d);
+        if (lane >= d) inc += n;
     }
-    __syncthreads();
+    const uint32_t start = inc - c;                   // start of bucket `lane`
+    if (tid < 2 * S) off[tid] = (uint16_t)inc;        // end of bucket k (off[0] = #big)
     uint4* R = a.recs + ((size_t)b * a.nseg + seg) * SEG;
     float4* Rn = a.recn + ((size_t)b * a.nseg + seg) * SEG;
-    for (int qi = tid; qi < nq; qi += EMIT_BLOCK) {
+    for (int q0 = tid - lane; q0 < nq; q0 += EMIT_BLOCK) {  // wave-uniform trip count: every lane takes part in the shuffle
+        const int qi = q0 + lane;
         const int sl = qi < nqf ? qi : SEG - 1 - (qi - nqf);
-        const uint32_t tag = qd[sl].x;
-        if (tag != 0xFFFFFFFFu) {
+        const uint32_t tag = qi < nq ? qd[sl].x : 0xFFFFFFFFu;
+        const bool have = tag != 0xFFFFFFFFu;
+        const uint32_t base = (uint32_t)__shfl((int)start, have ? (int)(tag >> 16) : 0);
+        if (have) {
             const float4 r = qa[sl];
-            const uint32_t slot = cnt[tag >> 16] + (tag & 0xFFFFu);
+            const uint32_t slot = base + (tag & 0xFFFFu);
             R[slot] = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
             Rn[slot] = qb[sl];
         }
     }
-    __syncthreads();  // the queue and the counters are recycled by the next item
-    }  // item loop
 }
 
 // ---- binned path, kernel 2: per (face, strip) LDS resolve + output ----------------------------------------
@@ -1139,18 +1105,6 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
                               const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
                               hipStream_t stream, int phases = 7);
 
-static int emit_cu_count() {
-    static int cus[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
-    }
-    return cus[dev];
-}
-
 int fr_launch_render_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                              int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
                              float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream) {
@@ -1225,21 +1179,8 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
                        ? (uint32_t)((0x100000000ull + (unsigned)g.nseg - 1) / (unsigned)g.nseg) : 0u;
     if (phases & 4)
         hipLaunchKernelGGL(pack_tri_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, tri, nver, ntri, tri4);
-    if (phases & 1) {
-        // persistent grid: at most 8 workgroups per CU (the LDS / wave-slot limit of this kernel), every workgroup the
-        // same number of items where the item count allows it (13,440 items -> 1,920 workgroups x 7)
-        const long long items = (long long)B * g.nseg;
-        const long long slots = 8ll * emit_cu_count();
-        long long ipw = (items + slots - 1) / slots;
-        if (env_int("FR_EMIT_PERSIST", 1) == 0) ipw = 1;  // A/B knob: one item per workgroup
-        long long grid = (items + ipw - 1) / ipw;
-        grid = (grid + 7) / 8 * 8;  // whole XCD groups (a workgroup whose share is empty exits at once)
-        if (grid > items) grid = items;
-        if (env_int("FR_EMIT_CAP", 8) == 8)
-            hipLaunchKernelGGL(raster_emit_kernel<8>, dim3((unsigned)grid), dim3(EMIT_BLOCK), 0, stream, a);
-        else
-            hipLaunchKernelGGL(raster_emit_kernel<1>, dim3((unsigned)grid), dim3(EMIT_BLOCK), 0, stream, a);
-    }
+    if (phases & 1)
+        hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
     if (!(phases & 2)) return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
     // 256-thread resolvers when several of them fit a CU's LDS side by side, 512 threads for wide strips
     const int rblk = env_int("FR_RESOLVE_BLOCK", g.lds <= 32 * 1024 ? 256 : 512);
