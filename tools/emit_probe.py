@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Development probe: emit-kernel variants (FR_EMIT_PERSIST = persistent item loop with next-item triangle prefetch,
-FR_EMIT_CAP = register budget) -- wall time of the kernel alone (back to back) and of the whole step; outputs compared."""
+"""Development probe: emit-kernel A/B knobs in one process, interleaved rounds (FR_EMIT_SCAN: phase C variant)."""
 import importlib
 import os
 import sys
@@ -23,8 +22,7 @@ def main():
     net = netm.FaceRecNet(mesh_data=A, batch_size=B, im_size=S, device=dev)
     plan = pipe.DecodeRenderPlan(net, B, S, S)
     plan.params.copy_(torch.as_tensor(synth.sample_params_batch(B, im_size=S, beta=0.7), device=dev))
-    os.environ["FR_EMIT_PERSIST"] = "0"
-    os.environ["FR_EMIT_CAP"] = "1"
+    os.environ["FR_EMIT_SCAN"] = "0"
     ref = [o.clone() for o in plan.step()]
     torch.cuda.synchronize()
 
@@ -38,14 +36,16 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / K * 1e6
 
-    for persist in ("1", "0"):
-        for cap in ("8", "1"):
-            os.environ["FR_EMIT_PERSIST"], os.environ["FR_EMIT_CAP"] = persist, cap
+    res = {"0": [], "1": []}
+    for rnd in range(5):
+        for v in ("0", "1"):
+            os.environ["FR_EMIT_SCAN"] = v
             outs = plan.step()
             torch.cuda.synchronize()
-            same = all(torch.equal(a, b) for a, b in zip(outs, ref))
-            r = [(round(wall(lambda: plan.render_phase(1)), 1), round(wall(plan.step), 1)) for _ in range(3)]
-            print("persist=%s cap=%s identical=%s  (emit alone us, step us): %s" % (persist, cap, same, r), flush=True)
+            assert all(torch.equal(a, b) for a, b in zip(outs, ref))
+            res[v].append((round(wall(lambda: plan.render_phase(1)), 1), round(wall(plan.step), 1)))
+    for v in ("0", "1"):
+        print("FR_EMIT_SCAN=%s (emit alone us, step us): %s" % (v, res[v]), flush=True)
 
 
 if __name__ == "__main__":
