@@ -968,25 +968,45 @@ __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArg
         }
     };
     if (m != 0 || bad) {
-        // pass 2, software pipelined: the (gradient, tri_ind) quad of the NEXT trip is requested before the twelve id
-        // gathers of the current one are consumed, so a trip costs one memory round trip instead of two
-        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), tv = make_float4(-1.f, -1.f, -1.f, -1.f);
-        if (tid < nq) { gv = g4[tid]; tv = t4[tid]; }
-        for (int i = tid; i < nq; i += BWD_BLOCK) {
-            const int t0 = bwd_tri_of(tv.x, ntri), t1 = bwd_tri_of(tv.y, ntri), t2 = bwd_tri_of(tv.z, ntri),
-                      t3 = bwd_tri_of(tv.w, ntri);
-            const int u0 = max(t0, 0), u1 = max(t1, 0), u2 = max(t2, 0), u3 = max(t3, 0);
-            const float a0 = tri0[u0], b0 = tri1[u0], c0 = tri2[u0];
-            const float a1 = tri0[u1], b1 = tri1[u1], c1 = tri2[u1];
-            const float a2 = tri0[u2], b2 = tri1[u2], c2 = tri2[u2];
-            const float a3 = tri0[u3], b3 = tri1[u3], c3 = tri2[u3];
-            const float4 gc = gv;
-            const int in = i + BWD_BLOCK;
-            if (in < nq) { gv = g4[in]; tv = t4[in]; }
-            if (t0 >= 0) add(gc.x, a0, b0, c0);
-            if (t1 >= 0) add(gc.y, a1, b1, c1);
-            if (t2 >= 0) add(gc.z, a2, b2, c2);
-            if (t3 >= 0) add(gc.w, a3, b3, c3);
+        // pass 2, software pipelined: TWO quads per lane per trip; the (gradient, tri_ind) quads of the NEXT trip are
+        // requested before the 24 id gathers of the current one are consumed, so a trip costs one memory round trip
+        constexpr int QU = 2;
+        float4 gv[QU], tv[QU];
+#pragma unroll
+        for (int u = 0; u < QU; u++) {
+            gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            tv[u] = make_float4(-1.f, -1.f, -1.f, -1.f);
+            const int i = tid + u * BWD_BLOCK;
+            if (i < nq) { gv[u] = g4[i]; tv[u] = t4[i]; }
+        }
+        for (int i0 = tid; i0 < nq; i0 += QU * BWD_BLOCK) {
+            int t[QU][4];
+            float id[QU][4][3];
+            float4 gc[QU];
+#pragma unroll
+            for (int u = 0; u < QU; u++) {
+                t[u][0] = bwd_tri_of(tv[u].x, ntri); t[u][1] = bwd_tri_of(tv[u].y, ntri);
+                t[u][2] = bwd_tri_of(tv[u].z, ntri); t[u][3] = bwd_tri_of(tv[u].w, ntri);
+                gc[u] = gv[u];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int tt = max(t[u][k], 0);
+                    id[u][k][0] = tri0[tt]; id[u][k][1] = tri1[tt]; id[u][k][2] = tri2[tt];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QU; u++) {
+                const int in = i0 + (QU + u) * BWD_BLOCK;
+                tv[u] = make_float4(-1.f, -1.f, -1.f, -1.f);
+                if (in < nq) { gv[u] = g4[in]; tv[u] = t4[in]; }
+            }
+#pragma unroll
+            for (int u = 0; u < QU; u++) {
+                if (t[u][0] >= 0) add(gc[u].x, id[u][0][0], id[u][0][1], id[u][0][2]);
+                if (t[u][1] >= 0) add(gc[u].y, id[u][1][0], id[u][1][1], id[u][1][2]);
+                if (t[u][2] >= 0) add(gc[u].z, id[u][2][0], id[u][2][1], id[u][2][2]);
+                if (t[u][3] >= 0) add(gc[u].w, id[u][3][0], id[u][3][1], id[u][3][2]);
+            }
         }
         for (int i = 4 * nq + tid; i < npix; i += BWD_BLOCK) {
             const int t = bwd_tri_of(ti[i], ntri);

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Copies the summaries of a GPU profile session (tools/gpu_run_final.sh -> gpurun_out/<session>/) into profiles/ under
+round-named files and refreshes profiles/pmc_traffic.json (the per-launch HBM traffic bench.py reports).
+Usage: python tools/collect_profiles.py gpurun_out/r2final round2"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def first(pattern):
+    f = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    return f[0] if f else None
+
+
+def kernel_stats(name, out):
+    f = first("%s/**/*kernel_stats.csv" % name)
+    if not f:
+        return None
+    shutil.copy(f, os.path.join(P, out))
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    hot = [r for r in rows if "fr::" in r["Name"]]
+    return {"total_gpu_ms": tot / 1e6, "hot_path_ms": sum(float(r["TotalDurationNs"]) for r in hot) / 1e6,
+            "hot_path_share": sum(float(r["TotalDurationNs"]) for r in hot) / tot,
+            "hot_path_kernels": {r["Name"].split("(")[0].replace("void ", ""): {"calls": int(r["Calls"]),
+                                                                                "avg_us": float(r["AverageNs"]) / 1e3}
+                                 for r in hot}}
+
+
+for j in ("bench", "bench_k20", "bench_graph"):
+    f = os.path.join(src, j + ".json")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(P, "%s_%s.json" % (tag, j)))
+kernel_stats("prof_bench", "%s_kernel_stats.csv" % tag)
+callers = {}
+for cfg, js in (("c3", "config3_fwd"), ("c4", "config4_train_shard"), ("c5", "config5_fine448_shard")):
+    rec = {}
+    f = os.path.join(src, js + ".json")
+    if os.path.exists(f) and os.path.getsize(f):
+        rec["line"] = json.load(open(f))
+    ks = kernel_stats("prof_" + cfg, "%s_%s_kernel_stats.csv" % (tag, js))
+    if ks:
+        rec["rocprofv3_kernel_stats"] = ks
+    callers[js] = rec
+json.dump(callers, open(os.path.join(P, "%s_caller_configs.json" % tag), "w"), indent=1)
+f = os.path.join(src, "pmc_summary.json")
+if os.path.exists(f):
+    pmc = json.load(open(f))
+    pmc = {k: v for k, v in pmc.items() if v.get("SQ_WAVES", 1) or v.get("FETCH_SIZE", 0)}
+    json.dump(pmc, open(os.path.join(P, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
+    dec = next(v for k, v in pmc.items() if "decode_ring_kernel" in k)
+    emit = next(v for k, v in pmc.items() if "raster_emit_kernel" in k)
+    res = next(v for k, v in pmc.items() if "resolve_write_kernel" in k)
+    json.dump({
+        "source": "rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- "
+                  "python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0, MI355X, %s kernels (profiles/%s_pmc.json); "
+                  "per launch, KiB * 1024.  decode streams 16 B/lane, so its FETCH_SIZE is doubled (MI355X_MICROARCH.md, "
+                  "HBM: gfx950 tallies 128-B requests at 64 B); the render kernels' dword gathers are uncalibrated and "
+                  "are reported raw." % (tag, tag),
+        "decode_bytes_per_launch": dec["hbm_bytes_fetch_x2"],
+        "render_bytes_per_launch": emit["hbm_bytes_raw"] + res["hbm_bytes_raw"],
+        "render_split": {"raster_emit_kernel": emit["hbm_bytes_raw"], "resolve_write_kernel": res["hbm_bytes_raw"]},
+        "batch": 64,
+        "kernels": ["decode_ring_kernel<13,2,8,2,16,64,4,true>", "raster_emit_kernel", "resolve_write_kernel<256>"],
+    }, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+for extra in ("kernel_timing.log",):
+    f = os.path.join(src, extra)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(P, "%s_%s" % (tag, extra)))
+f = os.path.join(ROOT, "gpurun_out", "parity_depth_vs_f64.json")
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(P, "%s_parity_depth_vs_f64.json" % tag))
+print(sorted(os.listdir(P)))
