@@ -627,8 +627,11 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             }
         }
         uint32_t tag = 0xFFFFFFFFu;
+        // (one LDS atomic per record: aggregating a wave's records per distinct bucket -- they fall into one to three --
+        // into one atomic each measured 3 us SLOWER per launch; same-address LDS atomics are cheap on gfx950)
+        uint32_t pos = 0;
+        if (emit) pos = atomicAdd(&cnt[bucket], 1u);
         if (emit) {
-            const uint32_t pos = atomicAdd(&cnt[bucket], 1u);
             tag = ((uint32_t)bucket << 16) | pos;
             qa[sl] = make_float4(__uint_as_float(rec.x), __uint_as_float(rec.y), __uint_as_float(rec.z),
                                  __uint_as_float(rec.w));
