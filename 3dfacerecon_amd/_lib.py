@@ -96,6 +96,10 @@ def _bind(L):
     L.fr_rendering_layer_forward.restype = _i
     L.fr_render_depth_backward.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     L.fr_render_depth_backward.restype = _i
+    L.fr_render_depth_backward_workspace_bytes.argtypes = [_i, _i]
+    L.fr_render_depth_backward_workspace_bytes.restype = ctypes.c_size_t
+    L.fr_render_depth_backward_ws.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
+    L.fr_render_depth_backward_ws.restype = _i
     L.fr_decode_packed_basis_bytes.argtypes = [_i, _i, _i]
     L.fr_decode_packed_basis_bytes.restype = ctypes.c_size_t
     L.fr_decode_pack_basis.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
@@ -117,7 +121,8 @@ def _bind(L):
 EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_render_depth_forward",
            "fr_render_depth_backward", "fr_decode_packed_basis_bytes", "fr_decode_pack_basis", "fr_decode_3dmm",
            "fr_decode_backward_workspace_bytes", "fr_decode_3dmm_backward", "fr_rendering_layer_forward",
-           "fr_render_depth_forward_phases", "fr_debug_render_geom", "fr_debug_div3_sweep"]
+           "fr_render_depth_forward_phases", "fr_debug_render_geom", "fr_debug_div3_sweep",
+           "fr_render_depth_backward_workspace_bytes", "fr_render_depth_backward_ws"]
 
 
 def lib():

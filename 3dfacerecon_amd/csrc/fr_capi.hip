@@ -72,14 +72,33 @@ int fr_rendering_layer_forward(const float* vertex, const float* tri, const floa
                                      depth, tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream);
 }
 
-int fr_render_depth_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
-                             int B, int nver, int ntri, int H, int W, void* hip_stream) {
+static int render_backward_checked(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
+                                   int B, int nver, int ntri, int H, int W, void* workspace, size_t ws_bytes,
+                                   void* hip_stream) {
     if (B < 0 || nver < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
     if ((size_t)B * nver == 0) return FR_OK;
     if (!vertex_grad) return FR_ERR_INVALID_ARG;
     if ((size_t)B * H * W > 0 && ntri > 0 && (!depth_grad || !tri || !tri_ind)) return FR_ERR_INVALID_ARG;
-    return fr_launch_render_backward(depth_grad, tri, tri_ind, vertex_grad, B, nver, ntri, H, W,
+    return fr_launch_render_backward(depth_grad, tri, tri_ind, vertex_grad, B, nver, ntri, H, W, workspace, ws_bytes,
                                      (hipStream_t)hip_stream);
+}
+
+int fr_render_depth_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
+                             int B, int nver, int ntri, int H, int W, void* hip_stream) {
+    return render_backward_checked(depth_grad, tri, tri_ind, vertex_grad, B, nver, ntri, H, W, nullptr, 0, hip_stream);
+}
+
+size_t fr_render_depth_backward_workspace_bytes(int B, int ntri) {
+    return (ntri > 0 && B > 0) ? fr_render_backward_workspace_bytes_impl(B, ntri) : 0;
+}
+
+int fr_render_depth_backward_ws(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
+                                int B, int nver, int ntri, int H, int W, void* workspace, size_t ws_bytes,
+                                void* hip_stream) {
+    if (workspace && (ws_bytes < fr_render_depth_backward_workspace_bytes(B, ntri) || ((uintptr_t)workspace & 15)))
+        return FR_ERR_WORKSPACE;
+    return render_backward_checked(depth_grad, tri, tri_ind, vertex_grad, B, nver, ntri, H, W, workspace, ws_bytes,
+                                   hip_stream);
 }
 
 size_t fr_decode_packed_basis_bytes(int N, int n_shape, int n_exp) {

@@ -863,9 +863,9 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
 // the schedule.  Here the sum is made ORDER-INDEPENDENT instead: every contribution c = (g * 1.0f) / 3.0f (fp32, as
 // :361 computes it) is converted EXACTLY to a 64-bit fixed-point integer (c * 2^k is exact in double; one llrint), the
 // integers are added with LDS integer atomics (associative => bit-reproducible whatever the order), and the total is
-// rounded to fp32 once.  k is chosen per face from max|c| so that the largest term has 40 significant bits below the
-// int64 headroom the H*W*3 possible terms need: every term is represented to 2^-41 of the face's largest term, i.e. the
-// result is the exactly rounded real sum up to  n_terms * 2^-41 * max|c|  -- at least as close to the real-number sum
+// rounded to fp32 once.  k is chosen per face from max|g| so that the largest term has at least 38 significant bits below
+// the int64 headroom the H*W*3 possible terms need: every term is represented to 2^-39 of the face's largest term, i.e.
+// the result is the exactly rounded real sum up to  n_terms * 2^-39 * max|c|  -- at least as close to the real-number sum
 // as the reference's sequential fp32 order (whose error grows with the partial sums), and identical run to run.
 // One workgroup owns one (face, vertex range) pair: it scans ALL the face's pixels (L2-resident planes) and keeps only
 // the contributions that land in its range, so no two workgroups ever add to the same vertex and nothing needs zeroing:
@@ -877,11 +877,13 @@ constexpr int BWD_RANGE_MAX = 16 * 1024;  // vertices per owner workgroup (8 B e
 
 struct BwdRenderArgs {
     const float* depth_grad;  // [B,H,W,1]
+    const int4* tri4;         // [ntri] pre-validated triangle table (pack_tri_kernel), or null: float ids from `tri`
     const float* tri;         // [3,ntri]
     const float* tri_ind;     // [B,H,W,1]
     float* vertex_grad;       // [B,3,nver]
     int nver, ntri, npix;     // npix = H*W
     int splits, range;        // owner workgroups per face, vertices per owner
+    const uint2* facemax;     // [B] {largest |g| bits over covered pixels, Inf/NaN flag} from bwd_prep_kernel (PACKED)
 };
 
 // the three vertex ids of pixel value `tv` (a float-stored triangle index, -1 on the background): false when the pixel
@@ -891,13 +893,70 @@ __device__ __forceinline__ int bwd_tri_of(float tv, int ntri) {
     return (t >= 0 && t < ntri) ? t : -1;
 }
 
+// Per-face scan for the workspace variant: largest |g| over the covered pixels + an Inf/NaN flag, one 1,024-thread
+// workgroup per face, no atomics (nothing to zero).  Runs in the same launch as the triangle packing (bwd_prep_kernel).
+__device__ __forceinline__ void bwd_face_max(const BwdRenderArgs& a, int b, uint32_t* red /*[2 * BWD_BLOCK / 64]*/, uint2* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int npix = a.npix;
+    const float* __restrict__ g = a.depth_grad + (size_t)b * npix;
+    const float* __restrict__ ti = a.tri_ind + (size_t)b * npix;
+    uint32_t m = 0, bad = 0;
+    constexpr int PU = 8;  // pixels per lane per trip, all loads issued before the first use
+    for (int i0 = tid; i0 < npix; i0 += PU * BWD_BLOCK) {
+        float gq[PU], tq[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const int i = min(i0 + u * BWD_BLOCK, npix - 1);
+            gq[u] = g[i];
+            tq[u] = ti[i];
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            if (i0 + u * BWD_BLOCK < npix && bwd_tri_of(tq[u], a.ntri) >= 0) {
+                const uint32_t v = __float_as_uint(gq[u]) & 0x7FFFFFFFu;
+                if (v >= 0x7F800000u) bad = 1; else m = max(m, v);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        m = max(m, (uint32_t)__shfl_xor((int)m, d));
+        bad |= (uint32_t)__shfl_xor((int)bad, d);
+    }
+    if (lane == 0) { red[wave] = m; red[BWD_BLOCK / 64 + wave] = bad; }
+    __syncthreads();
+    if (tid == 0) {
+        m = 0; bad = 0;
+        for (int w = 0; w < BWD_BLOCK / 64; w++) { m = max(m, red[w]); bad |= red[BWD_BLOCK / 64 + w]; }
+        *out = make_uint2(m, bad);
+    }
+}
+
+// Pre-kernel of the workspace variant: blocks [0, B) scan one face each (largest |g|), the rest pack the triangle list.
+__global__ __launch_bounds__(BWD_BLOCK) void bwd_prep_kernel(BwdRenderArgs a, int4* tri4, uint2* facemax, int B) {
+    __shared__ uint32_t red[2 * BWD_BLOCK / 64];
+    if ((int)blockIdx.x < B) {
+        bwd_face_max(a, (int)blockIdx.x, red, facemax + blockIdx.x);
+        return;
+    }
+    const int t = ((int)blockIdx.x - B) * BWD_BLOCK + threadIdx.x;
+    if (t >= a.ntri) return;
+    int p1, p2, p3;
+    const bool ok = id_ok(a.tri[t], a.nver, p1) & id_ok(a.tri[(size_t)a.ntri + t], a.nver, p2) &
+                    id_ok(a.tri[2 * (size_t)a.ntri + t], a.nver, p3);
+    tri4[t] = ok ? make_int4(p1 << 2, p2 << 2, p3 << 2, 1) : make_int4(0, 0, 0, 0);
+}
+
+// PACKED (workspace variant): the three vertex ids of a pixel's triangle come from the 16-byte table entry (one gather
+// per pixel instead of three -- the id gathers, repeated by every owner of the face, are what this kernel spends its time
+// on) and the face's largest |g| from the pre-kernel; otherwise float ids and an in-kernel scan.
+template <bool PACKED>
 __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArgs a) {
     // all LDS is dynamic (the launcher raises the dynamic limit to the CU's full 160 KiB, which leaves no room for
     // static objects): [range] accumulators, then two small per-wave reduction arrays
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];  // [range]
-    uint32_t* wmax = reinterpret_cast<uint32_t*>(acc + a.range);              // [BWD_BLOCK / 64]
-    uint32_t* wbad = wmax + BWD_BLOCK / 64;                                   // [BWD_BLOCK / 64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* red = reinterpret_cast<uint32_t*>(acc + a.range);               // [2 * BWD_BLOCK / 64]
+    const int tid = threadIdx.x;
     const int b = blockIdx.x / a.splits;
     const int sp = blockIdx.x - b * a.splits;
     const int v0 = sp * a.range;
@@ -909,111 +968,96 @@ __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArg
     const float* __restrict__ tri1 = a.tri + ntri;
     const float* __restrict__ tri2 = a.tri + 2 * (size_t)ntri;
     for (int i = tid; i < v1 - v0; i += BWD_BLOCK) acc[i] = 0ull;
-    // four pixels per lane per trip (16-byte loads) when the face's planes are 16-byte aligned
-    const bool vec = ((npix & 3) == 0) && ((((uintptr_t)g | (uintptr_t)ti) & 15) == 0);
-    const int nq = vec ? (npix >> 2) : 0;
-    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
-    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(ti);
 
-    // pass 1: the face's largest |c| over the covered pixels (max is order independent)
-    uint32_t m = 0, bad = 0;
-    {
-        auto see = [&](float gv, float tv) {
-            if (bwd_tri_of(tv, ntri) < 0) return;
-            const uint32_t u = __float_as_uint(gv * 1.0f / 3.0f) & 0x7FFFFFFFu;
-            if (u >= 0x7F800000u) bad = 1; else m = max(m, u);
-        };
-        for (int i = tid; i < nq; i += BWD_BLOCK) {
-            const float4 gv = g4[i], tv = t4[i];
-            see(gv.x, tv.x); see(gv.y, tv.y); see(gv.z, tv.z); see(gv.w, tv.w);
-        }
-        for (int i = 4 * nq + tid; i < npix; i += BWD_BLOCK) see(g[i], ti[i]);
+    // the face's largest |g| over the covered pixels (max is order independent); c = g/3 is at most two binades below,
+    // which the scale accounts for -- so the scan needs no division
+    uint32_t m, bad;
+    if constexpr (PACKED) {
+        const uint2 fm = a.facemax[b];
+        m = fm.x; bad = fm.y;
+    } else {
+        uint2* slot = reinterpret_cast<uint2*>(red + 2 * (BWD_BLOCK / 64));
+        bwd_face_max(a, b, red, slot);
+        __syncthreads();
+        m = slot->x; bad = slot->y;
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        m = max(m, (uint32_t)__shfl_xor((int)m, d));
-        bad |= (uint32_t)__shfl_xor((int)bad, d);
-    }
-    if (lane == 0) { wmax[wave] = m; wbad[wave] = bad; }
-    __syncthreads();
-    m = 0; bad = 0;
-#pragma unroll
-    for (int w = 0; w < BWD_BLOCK / 64; w++) { m = max(m, wmax[w]); bad |= wbad[w]; }
-
     float* gx = a.vertex_grad + (size_t)b * 3 * nver;
     float* gy = gx + nver;
     float* gz = gy + nver;
-    // scale 2^k: the largest term lands in [2^40, 2^41); up to 2^21 terms (3 per pixel) stay below 2^62
-    const int e = (int)(m >> 23) - 127;  // floor(log2 max|c|) for a normal float; -127 for subnormals / zero
+    // scale 2^k from e = floor(log2 max|g|): the largest term c = g/3 lands in [2^38, 2^40); up to 2^21 terms (3 per
+    // pixel) stay below 2^62
+    const int e = (int)(m >> 23) - 127;  // floor(log2 max|g|) for a normal float; -127 for subnormals / zero
     const double scale = ldexp(1.0, 40 - e);
     const double inv_scale = ldexp(1.0, e - 40);
     float* facc = reinterpret_cast<float*>(acc);  // Inf / NaN gradients: fp32 LDS atomics in the same buffer
     if (bad) {
         __syncthreads();
         for (int i = tid; i < v1 - v0; i += BWD_BLOCK) facc[i] = 0.0f;
-        __syncthreads();
     }
+    __syncthreads();
     // one contribution: c = (g * 1.0f) / 3.0f to the three vertices of triangle t that this workgroup owns
-    auto add = [&](float gv, float f1, float f2, float f3) {
-        const int p1 = f2i_x86(f1), p2 = f2i_x86(f2), p3 = f2i_x86(f3);
-        if ((unsigned)p1 >= (unsigned)nver || (unsigned)p2 >= (unsigned)nver || (unsigned)p3 >= (unsigned)nver) return;
+    auto add = [&](float gv, int p1, int p2, int p3, bool ids_ok) {
+        if (!ids_ok) return;
+        // ownership first: every owner of the face sees every pixel, but only ~1 / splits of them land in its range --
+        // the division and the fixed-point conversion are done for those only
+        const bool in1 = p1 >= v0 && p1 < v1, in2 = p2 >= v0 && p2 < v1, in3 = p3 >= v0 && p3 < v1;
+        if (!(in1 || in2 || in3)) return;
         const float c = gv * 1.0f / 3.0f;
         if (bad) {
-            if (p1 >= v0 && p1 < v1) atomicAdd(&facc[p1 - v0], c);
-            if (p2 >= v0 && p2 < v1) atomicAdd(&facc[p2 - v0], c);
-            if (p3 >= v0 && p3 < v1) atomicAdd(&facc[p3 - v0], c);
+            if (in1) atomicAdd(&facc[p1 - v0], c);
+            if (in2) atomicAdd(&facc[p2 - v0], c);
+            if (in3) atomicAdd(&facc[p3 - v0], c);
         } else {
             const unsigned long long q = (unsigned long long)__double2ll_rn((double)c * scale);  // exact product, one rounding
             if (q == 0ull) return;
-            if (p1 >= v0 && p1 < v1) atomicAdd(&acc[p1 - v0], q);
-            if (p2 >= v0 && p2 < v1) atomicAdd(&acc[p2 - v0], q);
-            if (p3 >= v0 && p3 < v1) atomicAdd(&acc[p3 - v0], q);
+            if (in1) atomicAdd(&acc[p1 - v0], q);
+            if (in2) atomicAdd(&acc[p2 - v0], q);
+            if (in3) atomicAdd(&acc[p3 - v0], q);
+        }
+    };
+    auto ids_of = [&](int tt, int& p1, int& p2, int& p3) -> bool {  // tt >= 0
+        if constexpr (PACKED) {
+            const int4 en = a.tri4[tt];
+            p1 = en.x >> 2; p2 = en.y >> 2; p3 = en.z >> 2;
+            return en.w != 0;
+        } else {
+            p1 = f2i_x86(tri0[tt]); p2 = f2i_x86(tri1[tt]); p3 = f2i_x86(tri2[tt]);
+            return (unsigned)p1 < (unsigned)nver && (unsigned)p2 < (unsigned)nver && (unsigned)p3 < (unsigned)nver;
         }
     };
     if (m != 0 || bad) {
-        // pass 2, software pipelined: TWO quads per lane per trip; the (gradient, tri_ind) quads of the NEXT trip are
-        // requested before the 24 id gathers of the current one are consumed, so a trip costs one memory round trip
-        constexpr int QU = 2;
-        float4 gv[QU], tv[QU];
+        // The scan.  Lane l of a trip's u-th slice takes pixel i0 + u * BLOCK: the 64 lanes of a gather instruction hold
+        // 64 CONSECUTIVE pixels -> neighbouring triangles -> a few cache lines of the id table per instruction (four
+        // pixels per lane, the obvious 16-byte-load mapping, puts every lane of a gather on its own line and runs the
+        // texture addresser at one lane per cycle: 21 us of this kernel).  Software pipelined: the (g, tri_ind) values of
+        // the NEXT trip are requested before the id gathers of the current one are consumed.
+        constexpr int QU = 8;
+        float gv[QU], tv[QU];
 #pragma unroll
         for (int u = 0; u < QU; u++) {
-            gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            tv[u] = make_float4(-1.f, -1.f, -1.f, -1.f);
             const int i = tid + u * BWD_BLOCK;
-            if (i < nq) { gv[u] = g4[i]; tv[u] = t4[i]; }
+            gv[u] = 0.f; tv[u] = -1.f;
+            if (i < npix) { gv[u] = g[i]; tv[u] = ti[i]; }
         }
-        for (int i0 = tid; i0 < nq; i0 += QU * BWD_BLOCK) {
-            int t[QU][4];
-            float id[QU][4][3];
-            float4 gc[QU];
+        for (int i0 = tid; i0 < npix; i0 += QU * BWD_BLOCK) {
+            int t[QU], id[QU][3];
+            bool ok[QU];
+            float gc[QU];
 #pragma unroll
             for (int u = 0; u < QU; u++) {
-                t[u][0] = bwd_tri_of(tv[u].x, ntri); t[u][1] = bwd_tri_of(tv[u].y, ntri);
-                t[u][2] = bwd_tri_of(tv[u].z, ntri); t[u][3] = bwd_tri_of(tv[u].w, ntri);
+                t[u] = bwd_tri_of(tv[u], ntri);
                 gc[u] = gv[u];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int tt = max(t[u][k], 0);
-                    id[u][k][0] = tri0[tt]; id[u][k][1] = tri1[tt]; id[u][k][2] = tri2[tt];
-                }
+                ok[u] = ids_of(max(t[u], 0), id[u][0], id[u][1], id[u][2]);
             }
 #pragma unroll
             for (int u = 0; u < QU; u++) {
                 const int in = i0 + (QU + u) * BWD_BLOCK;
-                tv[u] = make_float4(-1.f, -1.f, -1.f, -1.f);
-                if (in < nq) { gv[u] = g4[in]; tv[u] = t4[in]; }
+                tv[u] = -1.f;
+                if (in < npix) { gv[u] = g[in]; tv[u] = ti[in]; }
             }
 #pragma unroll
-            for (int u = 0; u < QU; u++) {
-                if (t[u][0] >= 0) add(gc[u].x, id[u][0][0], id[u][0][1], id[u][0][2]);
-                if (t[u][1] >= 0) add(gc[u].y, id[u][1][0], id[u][1][1], id[u][1][2]);
-                if (t[u][2] >= 0) add(gc[u].z, id[u][2][0], id[u][2][1], id[u][2][2]);
-                if (t[u][3] >= 0) add(gc[u].w, id[u][3][0], id[u][3][1], id[u][3][2]);
-            }
-        }
-        for (int i = 4 * nq + tid; i < npix; i += BWD_BLOCK) {
-            const int t = bwd_tri_of(ti[i], ntri);
-            if (t >= 0) add(g[i], tri0[t], tri1[t], tri2[t]);
+            for (int u = 0; u < QU; u++)
+                if (t[u] >= 0) add(gc[u], id[u][0], id[u][1], id[u][2], ok[u]);
         }
     }
     __syncthreads();
@@ -1219,8 +1263,14 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
+// workspace of the ws variant: the packed triangle table, then one {max, flag} pair per face
+size_t fr_render_backward_workspace_bytes_impl(int B, int ntri) {
+    return (ntri > 0 && B > 0) ? (size_t)ntri * sizeof(int4) + (size_t)B * sizeof(uint2) : 0;
+}
+
 int fr_launch_render_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
-                              int B, int nver, int ntri, int H, int W, hipStream_t stream) {
+                              int B, int nver, int ntri, int H, int W, void* workspace, size_t ws_bytes,
+                              hipStream_t stream) {
     using namespace fr;
     const size_t bytes = (size_t)B * 3 * nver * sizeof(float);
     const long long npix = (long long)H * W;
@@ -1238,9 +1288,27 @@ int fr_launch_render_backward(const float* depth_grad, const float* tri, const f
     BwdRenderArgs a;
     a.depth_grad = depth_grad; a.tri = tri; a.tri_ind = tri_ind; a.vertex_grad = vertex_grad;
     a.nver = nver; a.ntri = ntri; a.npix = (int)npix; a.splits = splits; a.range = range;
-    static unsigned char lds_ok[64];
-    if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_backward_kernel), lds_ok) != hipSuccess) return FR_ERR_LAUNCH;
-    hipLaunchKernelGGL(render_backward_kernel, dim3((unsigned)(B * splits)), dim3(BWD_BLOCK),
-                       (size_t)range * sizeof(unsigned long long) + 2 * (BWD_BLOCK / 64) * sizeof(uint32_t), stream, a);
+    // with a workspace one pre-kernel packs the float-stored triangle list (every pixel then costs one 16-byte id gather
+    // instead of three dword gathers) and scans each face's gradient plane for its largest magnitude once (instead of
+    // once per owner workgroup)
+    const bool packed = workspace && ws_bytes >= fr_render_backward_workspace_bytes_impl(B, ntri) &&
+                        (((uintptr_t)workspace) & 15) == 0 && ntri < (1 << 24);
+    int4* tri4 = reinterpret_cast<int4*>(workspace);
+    uint2* facemax = packed ? reinterpret_cast<uint2*>(tri4 + ntri) : nullptr;
+    a.tri4 = packed ? tri4 : nullptr;
+    a.facemax = facemax;
+    const size_t lds = (size_t)range * sizeof(unsigned long long) + 2 * (BWD_BLOCK / 64) * sizeof(uint32_t) + 16;
+    static unsigned char lds_ok[2][64];
+    if (packed) {
+        hipLaunchKernelGGL(bwd_prep_kernel, dim3((unsigned)(B + (ntri + BWD_BLOCK - 1) / BWD_BLOCK)), dim3(BWD_BLOCK), 0,
+                           stream, a, tri4, facemax, B);
+        if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_backward_kernel<true>), lds_ok[1]) != hipSuccess)
+            return FR_ERR_LAUNCH;
+        hipLaunchKernelGGL(render_backward_kernel<true>, dim3((unsigned)(B * splits)), dim3(BWD_BLOCK), lds, stream, a);
+    } else {
+        if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_backward_kernel<false>), lds_ok[0]) != hipSuccess)
+            return FR_ERR_LAUNCH;
+        hipLaunchKernelGGL(render_backward_kernel<false>, dim3((unsigned)(B * splits)), dim3(BWD_BLOCK), lds, stream, a);
+    }
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }

@@ -69,6 +69,16 @@ def _check_forward_shapes(ver, tri, texture, image):
         raise ValueError("The texture's batch is neither 1 nor the image batch")
 
 
+def _backward_call(h, g, tri_c, tri_ind, vertex_grad, B, nver, ntri, H, W, dev):
+    """fr_render_depth_backward_ws with its small workspace (packed triangle table + per-face gradient maxima)."""
+    L = h.lib()
+    nws = L.fr_render_depth_backward_workspace_bytes(B, ntri)
+    ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=dev)
+    rc = L.fr_render_depth_backward_ws(h.ptr(g), h.ptr(tri_c), h.ptr(tri_ind), h.ptr(vertex_grad), B, nver, ntri, H, W,
+                                       h.ptr(ws), nws, h.stream_ptr(dev))
+    h.check(rc, "fr_render_depth_backward")
+
+
 class _RenderDepth(torch.autograd.Function):
     """RenderDepth / RenderDepthGrad (render_depth_op.cc:535-589) as one autograd node."""
 
@@ -117,9 +127,7 @@ class _RenderDepth(torch.autograd.Function):
         vertex_grad = torch.empty((B, 3, nver), dtype=torch.float32, device=dev)
         g = h.require_gpu_f32(depth_grad, "depth_grad")
         with torch.cuda.device(dev):
-            rc = h.lib().fr_render_depth_backward(h.ptr(g), h.ptr(tri_c), h.ptr(tri_ind), h.ptr(vertex_grad), B, nver,
-                                                  ntri, H, W, h.stream_ptr(dev))
-        h.check(rc, "fr_render_depth_backward")
+            _backward_call(h, g, tri_c, tri_ind, vertex_grad, B, nver, ntri, H, W, dev)
         return vertex_grad, None, None, None
 
 
@@ -179,9 +187,7 @@ class _RenderingLayerFused(torch.autograd.Function):
         dg = dg.contiguous()
         vertex_grad = torch.empty((B, 3, nver), dtype=torch.float32, device=depth.device)
         with torch.cuda.device(depth.device):
-            rc = h.lib().fr_render_depth_backward(h.ptr(dg), h.ptr(tri_c), h.ptr(tri_ind), h.ptr(vertex_grad), B, nver,
-                                                  ntri, H, W, h.stream_ptr(depth.device))
-        h.check(rc, "fr_render_depth_backward")
+            _backward_call(h, dg, tri_c, tri_ind, vertex_grad, B, nver, ntri, H, W, depth.device)
         return vertex_grad, None, None, None
 
 
@@ -219,7 +225,5 @@ def render_depth_grad(depth_grad, ver, tri, depth, tri_ind, image):
     dev = g.device
     vertex_grad = torch.empty((B, 3, nver), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        rc = h.lib().fr_render_depth_backward(h.ptr(g), h.ptr(tri_c), h.ptr(ti), h.ptr(vertex_grad), B, nver, ntri, H, W,
-                                              h.stream_ptr(dev))
-    h.check(rc, "fr_render_depth_backward")
+        _backward_call(h, g, tri_c, ti, vertex_grad, B, nver, ntri, H, W, dev)
     return vertex_grad

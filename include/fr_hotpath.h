@@ -83,10 +83,24 @@ int fr_rendering_layer_forward(const float* vertex, const float* tri, const floa
  * Replaces RenderDepthOpGrad::Compute + functor RenderDepthGrad (render_depth_op.cc:470-528, 325-368;
  * render_depth_op.cu.cc:345-423) reached from the gradient registration at rendering_layer/ops.py:86-95.
  *   depth_grad [B,H,W,1], tri [3,ntri], tri_ind [B,H,W,1] (forward output) -> vertex_grad [B,3,nver]
- * vertex_grad is zero-filled, then every pixel with tri_ind >= 0 adds depth_grad/3 to the z row of its
- * triangle's three vertices; x and y rows stay 0 (render_depth_op.cc:359-363). */
+ * Every pixel with tri_ind >= 0 adds (depth_grad * 1.0f) / 3.0f to the z row of its triangle's three vertices; the x and
+ * y rows are 0 (render_depth_op.cc:359-363); all of vertex_grad is written.  The per-vertex sums are formed as exact
+ * 64-bit fixed-point integers and rounded once: the result is the correctly rounded real sum up to n * 2^-39 * max|term|
+ * per face and is bit-identical from run to run (the reference's serial loop has one fixed fp32 order; its CUDA twin
+ * uses order-dependent float atomics).  Images above 2^20 pixels return FR_ERR_UNSUPPORTED. */
 int fr_render_depth_backward(const float* depth_grad, const float* tri, const float* tri_ind,
                              float* vertex_grad, int B, int nver, int ntri, int H, int W, void* hip_stream);
+
+/* The same with a small caller-owned workspace (fr_render_depth_backward_workspace_bytes(B, ntri) = 16 bytes per
+ * triangle + 8 per face, 16-byte aligned): one pre-kernel converts and range-checks the float-stored triangle list into
+ * the workspace (every pixel then costs one 16-byte id gather instead of three dword gathers) and scans each face's
+ * gradient plane for its largest magnitude once instead of once per owner workgroup.  Results are bit-identical to
+ * fr_render_depth_backward (which is this function with workspace = NULL). */
+size_t fr_render_depth_backward_workspace_bytes(int B, int ntri);
+
+int fr_render_depth_backward_ws(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
+                                int B, int nver, int ntri, int H, int W, void* workspace, size_t ws_bytes,
+                                void* hip_stream);
 
 /* ---- 3DMM decode ---------------------------------------------------------------------------------------
  * Replaces FaceRecNet.vertices_transform + parse_pose_params + rotation_matrix_batch

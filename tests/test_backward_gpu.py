@@ -81,7 +81,7 @@ def test_background_and_bad_ids_are_skipped(oracle):
 def test_backward_is_bit_reproducible_and_the_rounded_exact_sum(oracle, full_assets, synth):
     """fr_render_depth_backward adds the contributions as exact fixed-point integers (order independent) and rounds once:
     two launches are bit-equal, and the result is the float64 sum of the fp32 terms (g*1.0f)/3.0f rounded to fp32, up to
-    the stated quantisation n * 2^-41 * max|term| -- closer to the real sum than the reference's sequential fp32 order."""
+    the stated quantisation n * 2^-39 * max|term| -- closer to the real sum than the reference's sequential fp32 order."""
     A = full_assets
     B = 4
     P = synth.sample_params_batch(B, beta=0.7, seed=21)
@@ -108,7 +108,7 @@ def test_backward_is_bit_reproducible_and_the_rounded_exact_sum(oracle, full_ass
     assert np.all(got[:, :2] == 0)
     cmax = np.abs(np.where(ti >= 0, c, 0)).max(axis=1)                  # per-face scale of the fixed-point grid
     bound = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64) * 0.5 + \
-        (nterm + 1) * 2.0 ** -40 * cmax[:, None]
+        (nterm + 1) * 2.0 ** -38 * cmax[:, None]
     err = np.abs(got[:, 2].astype(np.float64) - want)
     assert np.all(err <= bound), float((err / bound).max())
     # and it agrees with the oracle's sequential fp32 order to that order's own rounding error
@@ -140,3 +140,29 @@ def test_backward_inf_nan_gradients_and_small_batch_owners():
     assert np.isposinf(vg2[0, 2, 0]) and np.isposinf(vg2[0, 2, 2])
     assert np.isnan(vg2[0, 2, 1]) and np.isnan(vg2[0, 2, 3]) and np.isnan(vg2[0, 2, 5])
     assert np.isfinite(vg2[0, 2, 4]) and abs(vg2[0, 2, 4] - want[4]) < 1e-5
+
+
+def test_workspace_and_plain_entry_points_agree(oracle, full_assets, synth):
+    """fr_render_depth_backward_ws (packed triangle table, one id gather per pixel) == fr_render_depth_backward (float
+    ids, three gathers), bit for bit; bad ids / background handled identically."""
+    import ctypes
+    from conftest import pkg
+    h = pkg("_lib")
+    L = h.lib()
+    A = full_assets
+    B = 3
+    P = synth.sample_params_batch(B, beta=0.7, seed=8)
+    V = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0)
+    img = torch.zeros((B, 200, 200, 3), device="cuda:0")
+    tri = A["tri"].copy()
+    tri[1, 100:140] = 60000.0          # out-of-range ids: those triangles are skipped everywhere
+    depth, _, _, tind = ops().render_depth(_t(V), _t(tri), _t(A["vertex"]), img)
+    g = _t(np.random.RandomState(4).standard_normal((B, 200, 200, 1)))
+    got_ws = ops().render_depth_grad(g, _t(V), _t(tri), depth, tind, img)
+    plain = torch.empty_like(got_ws)
+    rc = L.fr_render_depth_backward(h.ptr(g), h.ptr(_t(tri)), h.ptr(tind), h.ptr(plain), B, V.shape[2], tri.shape[1], 200,
+                                    200, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(got_ws, plain)
+    assert float(got_ws[:, 2].abs().max()) > 0
