@@ -96,7 +96,7 @@ def _bind(L):
     L.fr_rendering_layer_forward.restype = _i
     L.fr_render_depth_backward.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     L.fr_render_depth_backward.restype = _i
-    L.fr_render_depth_backward_workspace_bytes.argtypes = [_i, _i]
+    L.fr_render_depth_backward_workspace_bytes.argtypes = [_i, _i, _i]
     L.fr_render_depth_backward_workspace_bytes.restype = ctypes.c_size_t
     L.fr_render_depth_backward_ws.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
     L.fr_render_depth_backward_ws.restype = _i

@@ -88,14 +88,14 @@ int fr_render_depth_backward(const float* depth_grad, const float* tri, const fl
     return render_backward_checked(depth_grad, tri, tri_ind, vertex_grad, B, nver, ntri, H, W, nullptr, 0, hip_stream);
 }
 
-size_t fr_render_depth_backward_workspace_bytes(int B, int ntri) {
-    return (ntri > 0 && B > 0) ? fr_render_backward_workspace_bytes_impl(B, ntri) : 0;
+size_t fr_render_depth_backward_workspace_bytes(int B, int H, int W) {
+    return (B > 0 && H > 0 && W > 0) ? fr_render_backward_workspace_bytes_impl(B, H, W) : 0;
 }
 
 int fr_render_depth_backward_ws(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
                                 int B, int nver, int ntri, int H, int W, void* workspace, size_t ws_bytes,
                                 void* hip_stream) {
-    if (workspace && (ws_bytes < fr_render_depth_backward_workspace_bytes(B, ntri) || ((uintptr_t)workspace & 15)))
+    if (workspace && (ws_bytes < fr_render_depth_backward_workspace_bytes(B, H, W) || ((uintptr_t)workspace & 15)))
         return FR_ERR_WORKSPACE;
     return render_backward_checked(depth_grad, tri, tri_ind, vertex_grad, B, nver, ntri, H, W, workspace, ws_bytes,
                                    hip_stream);

@@ -104,7 +104,7 @@ int fr_launch_rendering_layer(const float* vertex, const float* tri, const float
 int fr_launch_render_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
                               int B, int nver, int ntri, int H, int W, void* workspace, size_t ws_bytes,
                               hipStream_t stream);
-size_t fr_render_backward_workspace_bytes_impl(int B, int ntri);
+size_t fr_render_backward_workspace_bytes_impl(int B, int H, int W);
 size_t fr_render_workspace_bytes_impl(int B, int ntri, int H, int W);
 size_t fr_packed_basis_bytes(int N, int n_shape, int n_exp);
 int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,

@@ -877,13 +877,14 @@ constexpr int BWD_RANGE_MAX = 16 * 1024;  // vertices per owner workgroup (8 B e
 
 struct BwdRenderArgs {
     const float* depth_grad;  // [B,H,W,1]
-    const int4* tri4;         // [ntri] pre-validated triangle table (pack_tri_kernel), or null: float ids from `tri`
+    const int4* rec;          // [B,H,W] per-pixel records {p1,p2,p3,g bits} (bwd_records_kernel), or null: float ids
+    const uint2* partial;     // [B,chunks] {largest |g| bits, Inf/NaN flag} of each 1,024-pixel chunk
+    int B, chunks;
     const float* tri;         // [3,ntri]
     const float* tri_ind;     // [B,H,W,1]
     float* vertex_grad;       // [B,3,nver]
     int nver, ntri, npix;     // npix = H*W
     int splits, range;        // owner workgroups per face, vertices per owner
-    const uint2* facemax;     // [B] {largest |g| bits over covered pixels, Inf/NaN flag} from bwd_prep_kernel (PACKED)
 };
 
 // the three vertex ids of pixel value `tv` (a float-stored triangle index, -1 on the background): false when the pixel
@@ -893,8 +894,8 @@ __device__ __forceinline__ int bwd_tri_of(float tv, int ntri) {
     return (t >= 0 && t < ntri) ? t : -1;
 }
 
-// Per-face scan for the workspace variant: largest |g| over the covered pixels + an Inf/NaN flag, one 1,024-thread
-// workgroup per face, no atomics (nothing to zero).  Runs in the same launch as the triangle packing (bwd_prep_kernel).
+// Per-face scan: largest |g| over the covered pixels + an Inf/NaN flag, by one 1,024-thread
+// workgroup, no atomics (nothing to zero).  Used by the plain (no-workspace) variant.
 __device__ __forceinline__ void bwd_face_max(const BwdRenderArgs& a, int b, uint32_t* red /*[2 * BWD_BLOCK / 64]*/, uint2* out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npix = a.npix;
@@ -932,24 +933,68 @@ __device__ __forceinline__ void bwd_face_max(const BwdRenderArgs& a, int b, uint
     }
 }
 
-// Pre-kernel of the workspace variant: blocks [0, B) scan one face each (largest |g|), the rest pack the triangle list.
-__global__ __launch_bounds__(BWD_BLOCK) void bwd_prep_kernel(BwdRenderArgs a, int4* tri4, uint2* facemax, int B) {
-    __shared__ uint32_t red[2 * BWD_BLOCK / 64];
-    if ((int)blockIdx.x < B) {
-        bwd_face_max(a, (int)blockIdx.x, red, facemax + blockIdx.x);
-        return;
+// Pre-kernel of the workspace variant: ONE pass over all pixels of the batch resolves each pixel's triangle to its three
+// vertex ids (the scattered gathers, done once instead of once per owner workgroup) and writes a 16-byte record
+// {p1, p2, p3, g bits} per pixel -- p1 = -1 for pixels that contribute nothing (background, bad ids).  The owners then
+// STREAM the records.  Lane-consecutive pixels: a gather instruction's 64 lanes hold neighbouring triangles.
+constexpr int REC_PX = 1024;  // pixels per records-kernel workgroup (256 threads x 4)
+__global__ __launch_bounds__(256) void bwd_records_kernel(BwdRenderArgs a, int4* rec, uint2* partial, int chunks) {
+    __shared__ uint32_t red[8];
+    const int b = (int)blockIdx.x / chunks, ch = (int)blockIdx.x - b * chunks;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ tri0 = a.tri;
+    const float* __restrict__ tri1 = a.tri + a.ntri;
+    const float* __restrict__ tri2 = a.tri + 2 * (size_t)a.ntri;
+    const float* __restrict__ g = a.depth_grad + (size_t)b * a.npix;
+    const float* __restrict__ ti = a.tri_ind + (size_t)b * a.npix;
+    int4* __restrict__ out = rec + (size_t)b * a.npix;
+    constexpr int PU = REC_PX / 256;
+    const int i0 = ch * REC_PX + tid;
+    float gq[PU], tq[PU];
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const int i = min(i0 + u * 256, a.npix - 1);
+        gq[u] = g[i];
+        tq[u] = ti[i];
     }
-    const int t = ((int)blockIdx.x - B) * BWD_BLOCK + threadIdx.x;
-    if (t >= a.ntri) return;
-    int p1, p2, p3;
-    const bool ok = id_ok(a.tri[t], a.nver, p1) & id_ok(a.tri[(size_t)a.ntri + t], a.nver, p2) &
-                    id_ok(a.tri[2 * (size_t)a.ntri + t], a.nver, p3);
-    tri4[t] = ok ? make_int4(p1 << 2, p2 << 2, p3 << 2, 1) : make_int4(0, 0, 0, 0);
+    int t[PU];
+    float f[PU][3];
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        t[u] = bwd_tri_of(tq[u], a.ntri);
+        const int tt = max(t[u], 0);
+        f[u][0] = tri0[tt]; f[u][1] = tri1[tt]; f[u][2] = tri2[tt];
+    }
+    uint32_t m = 0, bad = 0;
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const int i = i0 + u * 256;
+        if (i < a.npix) {
+            const int p1 = f2i_x86(f[u][0]), p2 = f2i_x86(f[u][1]), p3 = f2i_x86(f[u][2]);
+            const bool ok = t[u] >= 0 && (unsigned)p1 < (unsigned)a.nver && (unsigned)p2 < (unsigned)a.nver &&
+                            (unsigned)p3 < (unsigned)a.nver;
+            out[i] = make_int4(ok ? p1 : -1, p2, p3, (int)__float_as_uint(gq[u]));
+            if (ok) {  // the face's largest |g| over the contributing pixels, in parts (max is order independent)
+                const uint32_t v = __float_as_uint(gq[u]) & 0x7FFFFFFFu;
+                if (v >= 0x7F800000u) bad = 1; else m = max(m, v);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        m = max(m, (uint32_t)__shfl_xor((int)m, d));
+        bad |= (uint32_t)__shfl_xor((int)bad, d);
+    }
+    if (lane == 0) { red[wave] = m; red[4 + wave] = bad; }
+    __syncthreads();
+    if (tid == 0)
+        partial[(size_t)b * chunks + ch] = make_uint2(max(max(red[0], red[1]), max(red[2], red[3])),
+                                                      red[4] | red[5] | red[6] | red[7]);
 }
 
-// PACKED (workspace variant): the three vertex ids of a pixel's triangle come from the 16-byte table entry (one gather
-// per pixel instead of three -- the id gathers, repeated by every owner of the face, are what this kernel spends its time
-// on) and the face's largest |g| from the pre-kernel; otherwise float ids and an in-kernel scan.
+// PACKED (workspace variant): the owners stream the per-pixel records of bwd_records_kernel (the id gathers -- repeated by
+// every owner of the face, they are what the plain variant spends its time on -- were done once); otherwise float ids
+// gathered in-kernel.
 template <bool PACKED>
 __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArgs a) {
     // all LDS is dynamic (the launcher raises the dynamic limit to the CU's full 160 KiB, which leaves no room for
@@ -957,8 +1002,18 @@ __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArg
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];  // [range]
     uint32_t* red = reinterpret_cast<uint32_t*>(acc + a.range);               // [2 * BWD_BLOCK / 64]
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / a.splits;
-    const int sp = blockIdx.x - b * a.splits;
+    // block -> (face, owner): blocks that share blockIdx % 8 share an XCD / L2; when the batch is a multiple of 8 the
+    // owners of a face are given ids of one residue class, so the face's planes / records are fetched into ONE L2 and
+    // re-read there, instead of once per owner
+    int b, sp;
+    if ((a.B & 7) == 0) {
+        const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+        b = (q / a.splits) * 8 + xcd;
+        sp = q % a.splits;
+    } else {
+        b = (int)blockIdx.x / a.splits;
+        sp = (int)blockIdx.x - b * a.splits;
+    }
     const int v0 = sp * a.range;
     const int v1 = min(a.nver, v0 + a.range);
     const int npix = a.npix, ntri = a.ntri, nver = a.nver;
@@ -972,9 +1027,25 @@ __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArg
     // the face's largest |g| over the covered pixels (max is order independent); c = g/3 is at most two binades below,
     // which the scale accounts for -- so the scan needs no division
     uint32_t m, bad;
+    const int4* __restrict__ rec = PACKED ? a.rec + (size_t)b * npix : nullptr;
     if constexpr (PACKED) {
-        const uint2 fm = a.facemax[b];
-        m = fm.x; bad = fm.y;
+        // the records kernel left the face's largest |g| in parts: one per 1,024-pixel chunk
+        m = 0; bad = 0;
+        for (int c = tid; c < a.chunks; c += BWD_BLOCK) {
+            const uint2 pm = a.partial[(size_t)b * a.chunks + c];
+            m = max(m, pm.x); bad |= pm.y;
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            m = max(m, (uint32_t)__shfl_xor((int)m, d));
+            bad |= (uint32_t)__shfl_xor((int)bad, d);
+        }
+        if (lane == 0) { red[wave] = m; red[BWD_BLOCK / 64 + wave] = bad; }
+        __syncthreads();
+        m = 0; bad = 0;
+#pragma unroll
+        for (int w = 0; w < BWD_BLOCK / 64; w++) { m = max(m, red[w]); bad |= red[BWD_BLOCK / 64 + w]; }
     } else {
         uint2* slot = reinterpret_cast<uint2*>(red + 2 * (BWD_BLOCK / 64));
         bwd_face_max(a, b, red, slot);
@@ -1015,22 +1086,24 @@ __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArg
             if (in3) atomicAdd(&acc[p3 - v0], q);
         }
     };
-    auto ids_of = [&](int tt, int& p1, int& p2, int& p3) -> bool {  // tt >= 0
-        if constexpr (PACKED) {
-            const int4 en = a.tri4[tt];
-            p1 = en.x >> 2; p2 = en.y >> 2; p3 = en.z >> 2;
-            return en.w != 0;
-        } else {
-            p1 = f2i_x86(tri0[tt]); p2 = f2i_x86(tri1[tt]); p3 = f2i_x86(tri2[tt]);
-            return (unsigned)p1 < (unsigned)nver && (unsigned)p2 < (unsigned)nver && (unsigned)p3 < (unsigned)nver;
+    if ((m != 0 || bad) && PACKED) {
+        // the owners stream the face's records: no gathers, no dependent loads
+        constexpr int QU = 8;
+        for (int i0 = tid; i0 < npix; i0 += QU * BWD_BLOCK) {
+            int4 rq[QU];
+#pragma unroll
+            for (int u = 0; u < QU; u++) rq[u] = rec[min(i0 + u * BWD_BLOCK, npix - 1)];
+#pragma unroll
+            for (int u = 0; u < QU; u++)
+                if (i0 + u * BWD_BLOCK < npix) add(__uint_as_float((uint32_t)rq[u].w), rq[u].x, rq[u].y, rq[u].z, rq[u].x >= 0);
         }
-    };
-    if (m != 0 || bad) {
+    }
+    if ((m != 0 || bad) && !PACKED) {
         // The scan.  Lane l of a trip's u-th slice takes pixel i0 + u * BLOCK: the 64 lanes of a gather instruction hold
         // 64 CONSECUTIVE pixels -> neighbouring triangles -> a few cache lines of the id table per instruction (four
         // pixels per lane, the obvious 16-byte-load mapping, puts every lane of a gather on its own line and runs the
-        // texture addresser at one lane per cycle: 21 us of this kernel).  Software pipelined: the (g, tri_ind) values of
-        // the NEXT trip are requested before the id gathers of the current one are consumed.
+        // texture addresser at one lane per cycle).  Software pipelined: the (g, tri_ind) values of the NEXT trip are
+        // requested before the id gathers of the current one are consumed.
         constexpr int QU = 8;
         float gv[QU], tv[QU];
 #pragma unroll
@@ -1047,7 +1120,10 @@ __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArg
             for (int u = 0; u < QU; u++) {
                 t[u] = bwd_tri_of(tv[u], ntri);
                 gc[u] = gv[u];
-                ok[u] = ids_of(max(t[u], 0), id[u][0], id[u][1], id[u][2]);
+                const int tt = max(t[u], 0);
+                id[u][0] = f2i_x86(tri0[tt]); id[u][1] = f2i_x86(tri1[tt]); id[u][2] = f2i_x86(tri2[tt]);
+                ok[u] = (unsigned)id[u][0] < (unsigned)nver && (unsigned)id[u][1] < (unsigned)nver &&
+                        (unsigned)id[u][2] < (unsigned)nver;
             }
 #pragma unroll
             for (int u = 0; u < QU; u++) {
@@ -1263,9 +1339,11 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
-// workspace of the ws variant: the packed triangle table, then one {max, flag} pair per face
-size_t fr_render_backward_workspace_bytes_impl(int B, int ntri) {
-    return (ntri > 0 && B > 0) ? (size_t)ntri * sizeof(int4) + (size_t)B * sizeof(uint2) : 0;
+// workspace of the ws variant: one 16-byte record per pixel of the batch + one {max, flag} pair per 1,024-pixel chunk
+size_t fr_render_backward_workspace_bytes_impl(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t npix = (size_t)H * W, chunks = (npix + fr::REC_PX - 1) / fr::REC_PX;
+    return (size_t)B * npix * sizeof(int4) + (size_t)B * chunks * sizeof(uint2);
 }
 
 int fr_launch_render_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
@@ -1288,20 +1366,21 @@ int fr_launch_render_backward(const float* depth_grad, const float* tri, const f
     BwdRenderArgs a;
     a.depth_grad = depth_grad; a.tri = tri; a.tri_ind = tri_ind; a.vertex_grad = vertex_grad;
     a.nver = nver; a.ntri = ntri; a.npix = (int)npix; a.splits = splits; a.range = range;
-    // with a workspace one pre-kernel packs the float-stored triangle list (every pixel then costs one 16-byte id gather
-    // instead of three dword gathers) and scans each face's gradient plane for its largest magnitude once (instead of
-    // once per owner workgroup)
-    const bool packed = workspace && ws_bytes >= fr_render_backward_workspace_bytes_impl(B, ntri) &&
-                        (((uintptr_t)workspace) & 15) == 0 && ntri < (1 << 24);
-    int4* tri4 = reinterpret_cast<int4*>(workspace);
-    uint2* facemax = packed ? reinterpret_cast<uint2*>(tri4 + ntri) : nullptr;
-    a.tri4 = packed ? tri4 : nullptr;
-    a.facemax = facemax;
+    // with a workspace one pre-kernel resolves every pixel to its vertex ids once (instead of once per owner workgroup)
+    // and the owners stream 16-byte records
+    const bool packed = workspace && ws_bytes >= fr_render_backward_workspace_bytes_impl(B, H, W) &&
+                        (((uintptr_t)workspace) & 15) == 0;
+    int4* rec = reinterpret_cast<int4*>(workspace);
+    const int chunks = (int)((npix + REC_PX - 1) / REC_PX);
+    uint2* partial = reinterpret_cast<uint2*>(rec + (size_t)B * npix);
+    a.rec = packed ? rec : nullptr;
+    a.partial = packed ? partial : nullptr;
+    a.B = B; a.chunks = chunks;
     const size_t lds = (size_t)range * sizeof(unsigned long long) + 2 * (BWD_BLOCK / 64) * sizeof(uint32_t) + 16;
     static unsigned char lds_ok[2][64];
     if (packed) {
-        hipLaunchKernelGGL(bwd_prep_kernel, dim3((unsigned)(B + (ntri + BWD_BLOCK - 1) / BWD_BLOCK)), dim3(BWD_BLOCK), 0,
-                           stream, a, tri4, facemax, B);
+        if ((long long)B * chunks > 0x7FFFFFFFll) return FR_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(bwd_records_kernel, dim3((unsigned)(B * chunks)), dim3(256), 0, stream, a, rec, partial, chunks);
         if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_backward_kernel<true>), lds_ok[1]) != hipSuccess)
             return FR_ERR_LAUNCH;
         hipLaunchKernelGGL(render_backward_kernel<true>, dim3((unsigned)(B * splits)), dim3(BWD_BLOCK), lds, stream, a);

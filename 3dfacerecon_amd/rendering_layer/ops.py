@@ -50,6 +50,22 @@ def compile(op=None):
 _host().lib()
 
 
+# Render workspace (hit records, bucket offsets, tables: ~330 MB at 64 faces) reused across calls: one buffer per
+# (device, stream), grown on demand.  The forward writes every part it later reads and nothing of it is needed by the
+# backward, so calls on one stream can share it; the reference cudaMallocs / cudaFrees six buffers per call
+# (render_depth_op.cu.cc:272-277, 335-340).
+_WS_CACHE = {}
+
+
+def _workspace(dev, nbytes):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+        _WS_CACHE[key] = ws
+    return ws
+
+
 def _check_forward_shapes(ver, tri, texture, image):
     # the OP_REQUIRES checks of RenderDepthOp::Compute (render_depth_op.cc:397-418), same messages
     if image.dim() != 4 or ver.dim() != 3 or tri.dim() != 2 or texture.dim() not in (2, 3):
@@ -70,9 +86,9 @@ def _check_forward_shapes(ver, tri, texture, image):
 
 
 def _backward_call(h, g, tri_c, tri_ind, vertex_grad, B, nver, ntri, H, W, dev):
-    """fr_render_depth_backward_ws with its small workspace (packed triangle table + per-face gradient maxima)."""
+    """fr_render_depth_backward_ws with its workspace (one 16-byte record per pixel)."""
     L = h.lib()
-    nws = L.fr_render_depth_backward_workspace_bytes(B, ntri)
+    nws = L.fr_render_depth_backward_workspace_bytes(B, H, W)
     ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=dev)
     rc = L.fr_render_depth_backward_ws(h.ptr(g), h.ptr(tri_c), h.ptr(tri_ind), h.ptr(vertex_grad), B, nver, ntri, H, W,
                                        h.ptr(ws), nws, h.stream_ptr(dev))
@@ -105,7 +121,7 @@ class _RenderDepth(torch.autograd.Function):
         L = h.lib()
         with torch.cuda.device(dev):
             ws_bytes = L.fr_render_depth_workspace_bytes(B, nver, ntri, H, W)
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+            ws = _workspace(dev, ws_bytes) if ws_bytes else None
             rc = L.fr_render_depth_forward(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), B, nver, ntri, H, W, 3, tex_batch,
                                            h.ptr(depth), h.ptr(tex_img), h.ptr(normal), h.ptr(tri_ind), h.ptr(ws),
                                            ws_bytes, h.stream_ptr(dev))
@@ -158,7 +174,7 @@ class _RenderingLayerFused(torch.autograd.Function):
         L = h.lib()
         with torch.cuda.device(dev):
             ws_bytes = L.fr_render_depth_workspace_bytes(B, nver, ntri, H, W)
-            ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+            ws = _workspace(dev, ws_bytes)
             rc = L.fr_rendering_layer_forward(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), h.ptr(img_c), B, nver, ntri, H, W,
                                               tex_batch, h.ptr(net_in), h.ptr(depth_img), h.ptr(depth), h.ptr(tri_ind),
                                               h.ptr(ws), ws_bytes, h.stream_ptr(dev))

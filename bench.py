@@ -178,9 +178,12 @@ def main():
     # EV_EVERY-th step only: an event pair costs a few microseconds of stream bubble, which at ~130 us per step would
     # otherwise tax every step by ~7 %.
     EV_EVERY = 8
-    blocks, ev_all = [], []
-    for _ in range(R):
-        ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for k in range(0, K, EV_EVERY)}
+    # (events for every block are created up front and the per-block max over ranks is taken after the last block, so
+    # that the host does nothing but barrier + synchronize + clock reads between two timed regions)
+    evs = [{k: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for k in range(0, K, EV_EVERY)} for _ in range(R)]
+    local, ev_all = [], []
+    for r in range(R):
+        ev = evs[r]
         dist_u.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -200,8 +203,9 @@ def main():
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         dist_u.barrier()
-        blocks.append(dist_u.max_over_ranks(t1 - t0, device=dev))
+        local.append(t1 - t0)
         ev_all.extend(ev.values())
+    blocks = [dist_u.max_over_ranks(t, device=dev) for t in local]
     order = sorted(range(R), key=lambda i: blocks[i])
     elapsed = blocks[order[(R - 1) // 2]]          # the median block (lower median for an even R)
     decode_ms = sum(e[0].elapsed_time(e[1]) for e in ev_all) / len(ev_all)

@@ -91,12 +91,12 @@ int fr_rendering_layer_forward(const float* vertex, const float* tri, const floa
 int fr_render_depth_backward(const float* depth_grad, const float* tri, const float* tri_ind,
                              float* vertex_grad, int B, int nver, int ntri, int H, int W, void* hip_stream);
 
-/* The same with a small caller-owned workspace (fr_render_depth_backward_workspace_bytes(B, ntri) = 16 bytes per
- * triangle + 8 per face, 16-byte aligned): one pre-kernel converts and range-checks the float-stored triangle list into
- * the workspace (every pixel then costs one 16-byte id gather instead of three dword gathers) and scans each face's
- * gradient plane for its largest magnitude once instead of once per owner workgroup.  Results are bit-identical to
- * fr_render_depth_backward (which is this function with workspace = NULL). */
-size_t fr_render_depth_backward_workspace_bytes(int B, int ntri);
+/* The same with a caller-owned workspace (fr_render_depth_backward_workspace_bytes(B, H, W): 16 bytes per pixel of the
+ * batch plus 8 per 1,024 pixels, 16-byte aligned): one pre-kernel resolves every pixel to its triangle's three vertex ids ONCE and writes a
+ * record per pixel; the accumulating workgroups (several per face) then stream the records instead of each repeating the
+ * scattered id gathers.  Results are bit-identical to fr_render_depth_backward (which is this function with
+ * workspace = NULL). */
+size_t fr_render_depth_backward_workspace_bytes(int B, int H, int W);
 
 int fr_render_depth_backward_ws(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
                                 int B, int nver, int ntri, int H, int W, void* workspace, size_t ws_bytes,
