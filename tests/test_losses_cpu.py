@@ -63,3 +63,54 @@ def test_pose_fidelity_and_total():
                                          ("fidelity_loss", 0.01), ("smoothness_loss", 700.0))}
     assert abs(float(L.combine_losses(d)) - LN.total_loss({k: float(v) for k, v in d.items()})) < 1e-6
     assert (L.LAMBDA_POSE, L.LAMBDA_GEO, L.LAMBDA_SH, L.LAMBDA_F, L.LAMBDA_SM) == (1e-3, 1e-6, 1e-3, 100.0, 1e-5)
+
+
+def _sfs_gather_worker(rank, world, port, q):
+    import importlib
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    d = importlib.import_module("3dfacerecon_amd.utils.dist")
+    L = importlib.import_module("3dfacerecon_amd.nets.losses")
+    d.init_from_env("gloo")
+    rs = np.random.RandomState(7)
+    B, H, W = 8, 4, 5
+    nrm = rs.standard_normal((B, H, W, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    alb = rs.uniform(0.2, 0.8, (B, H, W, 1)).astype(np.float32)
+    alb2 = rs.uniform(0.2, 0.8, (B, H, W, 1)).astype(np.float32)
+    im = rs.uniform(0, 1, (B, H, W, 1)).astype(np.float32)
+    t = lambda a: torch.as_tensor(a)  # noqa: E731
+    full = L.spherical_harmonics_intensity(t(alb), t(nrm), t(im), t(alb2), t(nrm)).numpy()      # the single-process estimate
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    local = L.spherical_harmonics_intensity(t(alb[sl]), t(nrm[sl]), t(im[sl]), t(alb2[sl]), t(nrm[sl])).numpy()
+    y = t(nrm[sl]).requires_grad_(True)
+    gathered = L.spherical_harmonics_intensity(t(alb[sl]), y, t(im[sl]), t(alb2[sl]), y, gather=True)
+    gathered.sum().backward()
+    q.put((rank, full[sl], local, gathered.detach().numpy(), bool(torch.isfinite(y.grad).all())))
+    d.finalize()
+
+
+def test_sfs_lighting_under_batch_sharding_gloo():
+    """the SfS lighting is one per-pixel least squares over the WHOLE batch (network.py:430-434).  Under batch
+    sharding each rank's own estimate differs from the single-process one; with gather=True (all-gather of the per-pixel
+    normals / intensities) every rank reproduces the single-process result for its shard."""
+    import torch.multiprocessing as mp
+    from test_callers import _free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sfs_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, want, local, gathered, finite in res:
+        np.testing.assert_allclose(gathered, want, rtol=2e-4, atol=2e-5)
+        assert np.abs(local - want).max() > 1e-3          # the per-shard estimator really is a different one
+        assert finite
