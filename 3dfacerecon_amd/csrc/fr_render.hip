@@ -57,6 +57,7 @@ struct RenderArgs {
     float* depth_img;      // [B,H,W,1] = max(depth, 1e-6)
     float wm1, hm1;        // (float)(W-1), (float)(H-1)
     uint32_t rows_magic;   // ceil(2^32 / rows): y / rows == umulhi(y, magic) for y, rows < 2^16
+    int use_filter;        // A/B knob FR_EMIT_FILTER: 0 sends every pixel through the fp64 sequence
     const int4* tri4;      // [ntri] pre-validated triangles {4*p1, 4*p2, 4*p3, valid} (pack_tri_kernel)
     uint32_t nseg_magic;   // ceil(2^32 / nseg): lid / nseg == umulhi(lid, magic) (launcher checks the range)
 };
@@ -586,16 +587,52 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             const int s0 = a.rows_magic ? (int)__umulhi((uint32_t)y_min, a.rows_magic) : y_min;
             const int s1 = a.rows_magic ? (int)__umulhi((uint32_t)y_max, a.rows_magic) : y_max;
             if (x_max - x_min < SMALL_W && y_max - y_min < SMALL_H) {
-                const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
+                // Inside test of the window's pixel centres.  The reference's test is an fp64 computation
+                // (render_depth_op.cc:90-121); its DECISION equals the exact-arithmetic one -- with D = v0 x v1,
+                // A = v2 x v1, B = v0 x v2 (2-D cross products): inside <=> A/D >= 0, B/D >= 0, (A+B)/D < 1 -- whenever the
+                // point is not within rounding distance of an edge and the triangle is not a sliver.  So the decision is
+                // first taken in fp32 WITH error bounds, and only pixels it cannot certify go through the fp64 operation
+                // sequence (about one lane in 10^4 on a sub-pixel mesh).  Bounds, with S = (largest |component| of v0, v1 --
+                // and hence of v2, see below)^2: every fp32 cross product is within 2^-21 S of its exact value (C = D - A - B within 2^-19 S); a
+                // pixel is certified when |D| >= 2^-8 S and |A|, |B|, |C| >= 2^-16 S.  Then the signs of the exact A, B, C
+                // are the computed ones, and the reference's fp64 u = A/D, v = B/D carry a relative error below 2^-22
+                // (numerators >= 2^-24 S^2 against 80 * 2^-53 S^2 of rounding), so its comparisons u < 0, v < 0, u > 1,
+                // v > 1, u + v < 1 -- whose exact margins are >= 2^-17 -- fall the same way.  NaN / Inf / huge / tiny
+                // (fp32 underflow) inputs fail the certificate and take the fp64 path.
+                const float v0x = x3 - x1, v0y = y3 - y1, v1x = x2 - x1, v1y = y2 - y1;
+                const float D = v0x * v1y - v0y * v1x;
+                // every tested pixel centre Q lies inside the triangle's bbox, so |Q - P1| <= max_i |P_i - P1| per axis:
+                // the largest component of v0, v1 bounds v2's as well and S is a per-triangle constant
+                const float M0 = fmaxf(fmaxf(fabsf(v0x), fabsf(v0y)), fmaxf(fabsf(v1x), fabsf(v1y)));
+                const float S = M0 * M0;
+                const float tm = 1.52587890625e-05f * S;  // 2^-16 S
+                // 2^-40 < M0 < 2^30: S and the thresholds are normal fp32 numbers, the error bounds hold; not a sliver
+                const bool tri_ok = a.use_filter && (M0 < 1073741824.0f) && (M0 > 9.094947017729282e-13f) &&
+                                    (fabsf(D) >= 0.00390625f * S);
+                const bool dpos = D > 0.0f;
                 // one flat loop over the window's pixels (not y / x nests): the compiler keeps it rolled, which holds the
-                // kernel at 56 VGPRs -- 8 waves per SIMD instead of 5
+                // kernel's VGPR count at the 8-waves-per-SIMD budget
                 const int bw = x_max - x_min + 1, npx = bw * (y_max - y_min + 1);
                 int dx = 0, bit = 0, yy = y_min;
-                uint32_t m = 0;
+                uint32_t m = 0, unsure = 0;
 #pragma clang loop unroll(disable)
                 for (int k = 0; k < npx; k++) {
-                    if (point_in_tri(ts, x_min + dx, yy)) m |= 1u << (bit + dx);
+                    const float v2x = (float)(x_min + dx) - x1, v2y = (float)yy - y1;
+                    const float A = v2x * v1y - v2y * v1x, Bq = v0x * v2y - v0y * v2x, C = (D - A) - Bq;
+                    const bool certain = tri_ok && fminf(fminf(fabsf(A), fabsf(Bq)), fabsf(C)) >= tm;
+                    const bool in = dpos ? fminf(fminf(A, Bq), C) > 0.0f : fmaxf(fmaxf(A, Bq), C) < 0.0f;
+                    const uint32_t bm = 1u << (bit + dx);
+                    if (!certain) unsure |= bm;
+                    else if (in) m |= bm;
                     if (++dx == bw) { dx = 0; bit += SMALL_W; yy++; }
+                }
+                if (unsure) {  // the reference's own operation sequence for the pixels the certificate left open
+                    const TriSetup ts = tri_setup(x1, y1, x2, y2, x3, y3);
+                    while (unsure) {
+                        const int bi = __ffs((int)unsure) - 1;
+                        unsure &= unsure - 1;
+                        if (point_in_tri(ts, x_min + (bi & 7), y_min + (bi >> 3))) m |= 1u << bi;
+                    }
                 }
                 rec.w = m;
                 emit = (m != 0);
@@ -1295,6 +1332,7 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     a.im_gray = im_gray; a.net_in = net_in; a.depth_img = depth_img;
     a.wm1 = (float)(W - 1);
     a.hm1 = (float)(H - 1);
+    a.use_filter = env_int("FR_EMIT_FILTER", 1);
     a.rows_magic = g.rows > 1 ? (uint32_t)((0x100000000ull + (unsigned)g.rows - 1) / (unsigned)g.rows) : 0u;
 
     const bool binned = g.binned_ok && ntri > 0 && !env_is("FR_RENDER_IMPL", "scan");

@@ -328,3 +328,55 @@ def test_very_wide_image_takes_the_scan_path(oracle):
     want = oracle.render_depth(ver, tri, tex, H, W)
     assert (want[3] >= 0).sum() > 100
     assert_render_equal(render_gpu(ver, tri, tex, H, W), want, "wide")
+
+
+def test_certified_fp32_inside_filter_adversarial(oracle):
+    """The emit kernel decides pixel-in-triangle in fp32 with error bounds and falls back to the reference's fp64 operation
+    sequence when it cannot certify the decision.  Triangles built so that an edge passes a pixel centre at distances from
+    1e-1 down to 1e-9 px on either side, slivers of aspect 10 .. 1e6, sub-ulp triangles, large (multi-pixel) and huge
+    coordinates: coverage, depth, normals bit-exact against the oracle."""
+    rs = np.random.RandomState(123)
+    H = W = 64
+    tris, zs = [], []
+
+    def add(p1, p2, p3):
+        tris.append((p1, p2, p3))
+        zs.append(rs.uniform(1, 50, 3))
+    for _ in range(6000):
+        c = rs.randint(2, 62, 2).astype(np.float64)                   # the pixel centre under attack
+        ang = rs.uniform(0, 2 * np.pi)
+        d = 10.0 ** rs.uniform(-9, -1) * rs.choice([-1, 1])           # signed distance of the edge from the centre
+        n = np.array([np.cos(ang), np.sin(ang)])
+        tdir = np.array([-n[1], n[0]])
+        L = 10.0 ** rs.uniform(-0.5, 0.7)                             # edge length 0.3 .. 5 px
+        a = c + d * n + tdir * L * rs.uniform(0.2, 0.8)
+        b = c + d * n - tdir * L * rs.uniform(0.2, 0.8)
+        apex = c + n * (10.0 ** rs.uniform(-6, 0.5)) * rs.choice([-1, 1]) + tdir * rs.uniform(-0.3, 0.3)   # slivers too
+        add(a, b, apex)
+    for _ in range(500):                                              # sub-ulp / tiny triangles around a centre
+        c = rs.randint(1, 63, 2).astype(np.float64)
+        s = 10.0 ** rs.uniform(-7, -2)
+        add(c + s * rs.uniform(-1, 1, 2), c + s * rs.uniform(-1, 1, 2), c + s * rs.uniform(-1, 1, 2))
+    for _ in range(300):                                              # multi-pixel triangles (window path, several pixels)
+        c = rs.uniform(4, 60, 2)
+        add(c + rs.uniform(-3.4, 3.4, 2), c + rs.uniform(-3.4, 3.4, 2) * [1, 0.5], c + rs.uniform(-3.4, 3.4, 2) * [1, 0.5])
+    nt = len(tris)
+    ver = np.zeros((2, 3, 3 * nt), np.float32)
+    P = np.array(tris, np.float64).reshape(nt * 3, 2)
+    ver[0, 0], ver[0, 1], ver[0, 2] = P[:, 0], P[:, 1], np.array(zs).reshape(-1)
+    ver[1] = ver[0]
+    ver[1, :2] = ver[1, :2] + np.float32(0.5)                         # second face: every centre half a pixel away
+    tri = np.arange(3 * nt, dtype=np.float32).reshape(nt, 3).T.copy()
+    tex = rs.uniform(0, 1, (1, 3, 3 * nt)).astype(np.float32)
+    want = oracle.render_depth(ver, tri, tex, H, W)
+    assert (want[3] >= 0).mean() > 0.3
+    assert_render_equal(render_gpu(ver, tri, tex, H, W), want, "certified filter")
+    # a few hand-made extremes: exact zero-area, vertex on the centre, huge and tiny scales
+    v = np.zeros((1, 3, 15), np.float32)
+    pts = [(5, 5), (7, 5), (6, 5), (10, 10), (12, 10), (10, 12), (20, 20), (20 + 1e-7, 20), (20, 20 + 1e-7),
+           (30.5, 30.5), (3e9, 30), (30, 3e9), (40, 40), (40.00001, 40.00002), (40.00002, 40.00001)]
+    for k, (x, y) in enumerate(pts):
+        v[0, 0, k], v[0, 1, k], v[0, 2, k] = x, y, 3 + k
+    t5 = np.arange(15, dtype=np.float32).reshape(5, 3).T.copy()
+    x5 = rs.uniform(0, 1, (1, 3, 15)).astype(np.float32)
+    assert_render_equal(render_gpu(v, t5, x5, H, W), oracle.render_depth(v, t5, x5, H, W), "extremes")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development probe: emit-kernel A/B knobs in one process, interleaved rounds (FR_EMIT_AGG: wave-aggregated record-slot atomics)."""
+"""Development probe: emit-kernel A/B knobs in one process, interleaved rounds (FR_EMIT_FILTER: certified fp32 inside test)."""
 import importlib
 import os
 import sys
@@ -22,7 +22,7 @@ def main():
     net = netm.FaceRecNet(mesh_data=A, batch_size=B, im_size=S, device=dev)
     plan = pipe.DecodeRenderPlan(net, B, S, S)
     plan.params.copy_(torch.as_tensor(synth.sample_params_batch(B, im_size=S, beta=0.7), device=dev))
-    os.environ["FR_EMIT_AGG"] = "0"
+    os.environ["FR_EMIT_FILTER"] = "0"
     ref = [o.clone() for o in plan.step()]
     torch.cuda.synchronize()
 
@@ -39,13 +39,13 @@ def main():
     res = {"0": [], "1": []}
     for rnd in range(5):
         for v in ("0", "1"):
-            os.environ["FR_EMIT_AGG"] = v
+            os.environ["FR_EMIT_FILTER"] = v
             outs = plan.step()
             torch.cuda.synchronize()
             assert all(torch.equal(a, b) for a, b in zip(outs, ref))
             res[v].append((round(wall(lambda: plan.render_phase(1)), 1), round(wall(plan.step), 1)))
     for v in ("0", "1"):
-        print("FR_EMIT_AGG=%s (emit alone us, step us): %s" % (v, res[v]), flush=True)
+        print("FR_EMIT_FILTER=%s (emit alone us, step us): %s" % (v, res[v]), flush=True)
 
 
 if __name__ == "__main__":
