@@ -277,7 +277,11 @@ def main():
                                    "%dx%d, fp32, all four output planes" % (B, H, W),
                        "faces_per_gpu": B, "nver": N, "ntri": T, "n_shape": net.ndim_shape, "n_exp": net.ndim_exp,
                        "sampler": "sample_test.py:23-38 beta=0.7 seed=3456+rank", "coverage": cov,
-                       "sharding": "batch over ranks, no data-path collective"},
+                       "sharding": "batch over ranks, no data-path collective",
+                       "constants": "the packed basis (fr_decode_pack_basis) and the pre-validated triangle table "
+                                    "(fr_render_depth_forward_phases, phase 4) are built once per plan: both are "
+                                    "tf.constants of the reference model (network.py:41-43, 178); a caller that repacks the "
+                                    "triangle list every call (fr_render_depth_forward) pays one more 5 us kernel per step"},
             "roofline": dominant,
             "kernels": kernels,
             "pipeline_hbm": {"bytes_per_face": ab["pipeline"],
