@@ -13,8 +13,8 @@ import threading
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.path.join(_PKG_DIR, "libfr_hotpath.so")
-SOURCES = ["fr_capi.hip", "fr_render.hip", "fr_decode.hip", "fr_decode_bwd.hip"]
-HEADERS = [os.path.join(_CSRC, "fr_common.h"), os.path.join(_PKG_DIR, "..", "include", "fr_hotpath.h")]
+SOURCES = ["fr_capi.hip", "fr_render.hip", "fr_decode.hip", "fr_decode_q.hip", "fr_decode_bwd.hip"]
+HEADERS = [os.path.join(_CSRC, "fr_common.h"), os.path.join(_CSRC, "fr_decode_shared.h"), os.path.join(_PKG_DIR, "..", "include", "fr_hotpath.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]  # single-lane LDS atomics stay single instructions
 
@@ -106,6 +106,10 @@ def _bind(L):
     L.fr_decode_pack_basis.restype = _i
     L.fr_decode_3dmm.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp]
     L.fr_decode_3dmm.restype = _i
+    L.fr_decode_set_arith.argtypes = [_i]
+    L.fr_decode_set_arith.restype = _i
+    L.fr_decode_get_arith.argtypes = []
+    L.fr_decode_get_arith.restype = _i
     L.fr_decode_backward_workspace_bytes.argtypes = [_i, _i, _i, _i]
     L.fr_decode_backward_workspace_bytes.restype = ctypes.c_size_t
     L.fr_decode_3dmm_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp,
@@ -122,7 +126,8 @@ EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_r
            "fr_render_depth_backward", "fr_decode_packed_basis_bytes", "fr_decode_pack_basis", "fr_decode_3dmm",
            "fr_decode_backward_workspace_bytes", "fr_decode_3dmm_backward", "fr_rendering_layer_forward",
            "fr_render_depth_forward_phases", "fr_debug_render_geom", "fr_debug_div3_sweep",
-           "fr_render_depth_backward_workspace_bytes", "fr_render_depth_backward_ws"]
+           "fr_render_depth_backward_workspace_bytes", "fr_render_depth_backward_ws", "fr_decode_set_arith",
+           "fr_decode_get_arith"]
 
 
 def lib():

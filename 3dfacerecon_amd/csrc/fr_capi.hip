@@ -126,6 +126,9 @@ int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R
                             (hipStream_t)hip_stream);
 }
 
+int fr_decode_set_arith(int mode) { return fr_decode_arith_set(mode); }
+int fr_decode_get_arith(void) { return fr_decode_arith_get(); }
+
 size_t fr_decode_backward_workspace_bytes(int B, int N, int n_shape, int n_exp) {
     (void)n_shape; (void)n_exp;
     if (B <= 0 || N <= 0) return 0;

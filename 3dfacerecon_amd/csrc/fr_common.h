@@ -111,6 +111,14 @@ int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc
                          void* packed, hipStream_t stream);
 int fr_launch_decode(const float* params, const void* packed, const float* R_override, int B, int N, int n_shape,
                      int n_exp, float im_size, float* vertex_proj, hipStream_t stream);
+size_t fr_packed_q_bytes(int N, int n_shape, int n_exp);
+bool fr_decode_q_supported(int n_shape, int n_exp);
+int fr_launch_pack_q(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
+                     void* qimage, hipStream_t stream);
+int fr_launch_decode_q(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
+                       int n_exp, float im_size, float* vertex_proj, int cus, hipStream_t stream);
+int fr_decode_arith_get();
+int fr_decode_arith_set(int mode);
 size_t fr_decode_backward_workspace_impl(int N);
 int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
                               const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N, int ns,

@@ -14,21 +14,15 @@
 // the epilogue (+mu, 3x3 f*R transform, +t3d, y-flip) is fused and the result is written straight to
 // [B,3,N] -- none of the [B,N,3] temporaries / transposes of network.py:153-169 exist.
 // Bound: fp32 MFMA rate at B = 64 (72.8 MFLOP per face; 157 TF peak) and the 146 MB basis stream below that.
-#include "fr_common.h"
+#include "fr_decode_shared.h"
 
 namespace fr {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-
-constexpr int TILE_V = 16;      // vertices per wave tile (MFMA M)
 constexpr int KGROUP = 16;      // k values per packed group (4 k-steps of 4)
-constexpr int MAXB = 64;        // batch columns per pass (4 MFMA column blocks of 16)
 // waves per persistent workgroup (one per CU): 16 (4 per SIMD, <= 128 VGPRs) for 32-column work items, 12 (3 per
 // SIMD, <= 168 VGPRs) for 64-column work items
 
 __host__ __device__ inline int groups_of(int n) { return (n + KGROUP - 1) / KGROUP; }
-__host__ __device__ inline int tiles_of(int N) { return (N + TILE_V - 1) / TILE_V; }
 
 // Packed image:  A[tile][g][c][lane] as float4 (4 consecutive k-steps), then mu[tile][c][16].
 //   A[tile][g][c][lane][j] = basis_c[16*tile + (lane&15)][16*g' + 4*j + (lane>>4)]   (0 when out of range)
@@ -73,38 +67,6 @@ __global__ __launch_bounds__(256) void pack_basis_kernel(const float* __restrict
         long long p = tile * TILE_V + q;
         mu_p[i] = (p < N) ? mu[(size_t)c * N + p] : 0.f;
     }
-}
-
-struct DecodeArgs {
-    const float* params;      // [B, 7+ns+ne]
-    const float4* A;          // packed basis
-    const float* mu_p;        // packed mu
-    const float* R_override;  // [B,9] or null
-    float* out;               // [B,3,N]
-    int B, N, ns, ne;
-    int b0;                   // first batch column of this pass
-    int halves;               // column-block groups per tile: a work item is (tile, half)
-    float im_size;
-};
-
-// rotation in float64 exactly as network.py:276-290: R = (R_pitch . R_yaw) . R_roll, 3-term dots, no FMA.
-__device__ __forceinline__ void mat3_mul(const double* A, const double* Bm, double* C) {
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            C[3 * i + j] = (A[3 * i + 0] * Bm[0 + j] + A[3 * i + 1] * Bm[3 + j]) + A[3 * i + 2] * Bm[6 + j];
-}
-__device__ __forceinline__ void rotation_from_sincos(double sp, double cp, double sy, double cy, double st, double ct,
-                                                     float* R9) {
-    double Rp[9] = {1, 0, 0, 0, cp, sp, 0, -sp, cp};
-    double Ry[9] = {cy, 0, -sy, 0, 1, 0, sy, 0, cy};
-    double Rr[9] = {ct, st, 0, -st, ct, 0, 0, 0, 1};
-    double PY[9], Rm[9];
-    mat3_mul(Rp, Ry, PY);
-    mat3_mul(PY, Rr, Rm);
-#pragma unroll
-    for (int i = 0; i < 9; i++) R9[i] = (float)Rm[i];
 }
 
 // One MFMA k-group: 4 k-steps of v_mfma_f32_16x16x4_f32 for NBW column blocks of one coordinate row-block.
@@ -169,28 +131,6 @@ __device__ __forceinline__ void mfma_group1(float4 a0, const float* Plg, const i
     mfma_step<NBW>(a0.w, ldb<NBW>(Plg, sw, 3), acc0);
 }
 
-// Work distribution shared by the decode kernels.  A workgroup works on `slots` tiles at a time (slot = wave / halves).
-// Tiles are dealt in adjacent PAIRS: slots 2s and 2s+1 of a workgroup take tiles 2P and 2P+1, so the two 64-byte pieces
-// a pair writes into each output row come from one CU at about the same time; pair P goes to workgroup perm(P % grid) of
-// round P / grid, where perm keeps consecutive pairs on the same XCD (workgroup b runs on XCD b % 8), so the partial
-// cache lines at the seams still meet in one L2.  Dealing pairs round-robin keeps the last, partial round to at most one
-// extra pair per CU.
-struct TileWalk {
-    int first, stride;
-};
-__device__ __forceinline__ TileWalk tile_walk(int slot, int slots, int b, int grid) {
-    const int pb = (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b;
-    TileWalk w;
-    if (slots & 1) {  // odd slot count (not used by the launchers): plain round-robin over tiles
-        w.first = slot * grid + pb;
-        w.stride = slots * grid;
-    } else {
-        w.first = 2 * ((slot >> 1) * grid + pb) + (slot & 1);
-        w.stride = slots * grid;  // = 2 * (slots / 2) * grid
-    }
-    return w;
-}
-
 // Persistent kernel: one workgroup per CU (16 waves).  The parameters are laid into LDS once per CU; then every wave
 // walks work items (tile of 16 vertices, group of NBW batch-column blocks).  With B = 64 an item is half a tile
 // (NBW = 2): 6,652 items over 1,024 SIMDs balance to within 8 % of the MFMA floor, where whole tiles (3,326) would leave
@@ -241,83 +181,8 @@ __device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem
             }
         }
     }
-    // pose: the 3*MB float64 sincos evaluations are spread over 3*MB threads, then MB threads assemble f*R and t
-    if (tid < 3 * MB && !a.R_override) {
-        const int b = tid / 3, ang = tid - 3 * b;
-        double sn = 0.0, cs = 1.0;
-        if (b < nbatch) sincos((double)a.params[(size_t)(a.b0 + b) * nd + ang], &sn, &cs);
-        SC[(b * 3 + ang) * 2 + 0] = sn;
-        SC[(b * 3 + ang) * 2 + 1] = cs;
-    }
-    __syncthreads();
-    if (tid < MB) {
-        float m[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) m[i] = 0.f;
-        if (tid < nbatch) {
-            const float* pr = a.params + (size_t)(a.b0 + tid) * nd;
-            float R[9];
-            if (a.R_override) {
-#pragma unroll
-                for (int i = 0; i < 9; i++) R[i] = a.R_override[(size_t)(a.b0 + tid) * 9 + i];
-            } else {
-                const double* sc = SC + tid * 6;
-                rotation_from_sincos(sc[0], sc[1], sc[2], sc[3], sc[4], sc[5], R);
-            }
-            float f = pr[6];
-#pragma unroll
-            for (int i = 0; i < 9; i++) m[i] = f * R[i];  // f (.) R elementwise, network.py:163-165
-            m[9] = pr[3];
-            m[10] = pr[4];
-            m[11] = pr[5];
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++) Mt[tid * 12 + i] = m[i];
-    }
-    __syncthreads();
+    pose_prologue<MB>(a, Mt, SC, tid, nd, nbatch);
 
-}
-
-// Fused epilogue of one work item: 3x3 (f.R) transform, +t3d, y flip, store [B,3,N].
-template <int NBW>
-__device__ __forceinline__ void decode_store(const DecodeArgs& a, const f32x4 (&s0)[NBW], const f32x4 (&s1)[NBW],
-                                             const f32x4 (&s2)[NBW], const float* Mt, int tile, int hf, int lane,
-                                             int nbatch, int N) {
-    const int p0v = tile * TILE_V + 4 * (lane >> 4);  // first of this lane's 4 vertices
-#pragma unroll
-    for (int nb = 0; nb < NBW; nb++) {
-        const int bb = 16 * (hf * NBW + nb) + (lane & 15);
-        if (bb >= nbatch) continue;
-        const float* m = Mt + bb * 12;
-        f32x4 px, py, pz;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float vx = s0[nb][r], vy = s1[nb][r], vz = s2[nb][r];
-            const float qx = __builtin_fmaf(m[2], vz, __builtin_fmaf(m[1], vy, m[0] * vx)) + m[9];
-            const float qy = __builtin_fmaf(m[5], vz, __builtin_fmaf(m[4], vy, m[3] * vx)) + m[10];
-            const float qz = __builtin_fmaf(m[8], vz, __builtin_fmaf(m[7], vy, m[6] * vx)) + m[11];
-            px[r] = qx;
-            py[r] = (a.im_size - qy) - 1.0f;  // network.py:168
-            pz[r] = qz;
-        }
-        float* ox = a.out + ((size_t)(a.b0 + bb) * 3) * N + p0v;
-        float* oy = ox + N;
-        float* oz = oy + N;
-        if (p0v + 3 < N) {
-            *reinterpret_cast<f32x4u*>(ox) = px;
-            *reinterpret_cast<f32x4u*>(oy) = py;
-            *reinterpret_cast<f32x4u*>(oz) = pz;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                if (p0v + r < N) {
-                    ox[r] = px[r];
-                    oy[r] = py[r];
-                    oz[r] = pz[r];
-                }
-            }
-        }
-    }
 }
 
 template <int NBW, int DEC_WAVES>
@@ -567,11 +432,34 @@ void decode_ring_kernel(DecodeArgs a) {
 
 }  // namespace fr
 
-size_t fr_packed_basis_bytes(int N, int n_shape, int n_exp) {
+// The packed buffer holds two images of the basis: the f32 A-fragment image of this file, then (256-byte aligned) the
+// Q30 digit image of fr_decode_q.hip.
+static size_t packed_f32_bytes(int N, int n_shape, int n_exp) {
     using namespace fr;
     size_t tiles = (size_t)tiles_of(N);
     size_t G = (size_t)groups_of(n_shape) + groups_of(n_exp);
     return tiles * G * 3 * 64 * sizeof(float4) + tiles * 3 * TILE_V * sizeof(float);
+}
+static size_t packed_q_offset(int N, int n_shape, int n_exp) {
+    return (packed_f32_bytes(N, n_shape, n_exp) + 255) & ~(size_t)255;
+}
+size_t fr_packed_basis_bytes(int N, int n_shape, int n_exp) {
+    return packed_q_offset(N, n_shape, n_exp) + (fr_decode_q_supported(n_shape, n_exp) ? fr_packed_q_bytes(N, n_shape, n_exp) : 0);
+}
+
+// Arithmetic of the basis blend: FR_DECODE_ARITH_Q30 (default) or FR_DECODE_ARITH_F32 (the k-ordered fmaf chain).
+static int g_decode_arith = -1;
+int fr_decode_arith_get() {
+    if (g_decode_arith < 0) {
+        const char* e = getenv("FR_DECODE_ARITH");
+        g_decode_arith = (e && !strcmp(e, "f32")) ? FR_DECODE_ARITH_F32 : FR_DECODE_ARITH_Q30;
+    }
+    return g_decode_arith;
+}
+int fr_decode_arith_set(int mode) {
+    if (mode != FR_DECODE_ARITH_Q30 && mode != FR_DECODE_ARITH_F32) return FR_ERR_INVALID_ARG;
+    g_decode_arith = mode;
+    return FR_OK;
 }
 
 int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
@@ -584,7 +472,10 @@ int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc
     float* mu_p = reinterpret_cast<float*>(A + tiles * G * 3 * 64);
     hipLaunchKernelGGL(pack_basis_kernel, dim3(2048), dim3(256), 0, stream, mu, pc_shape, pc_exp, N, n_shape, n_exp, A,
                        mu_p);
-    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return FR_ERR_LAUNCH;
+    if (!fr_decode_q_supported(n_shape, n_exp)) return FR_OK;
+    return fr_launch_pack_q(mu, pc_shape, pc_exp, N, n_shape, n_exp,
+                            reinterpret_cast<char*>(packed) + packed_q_offset(N, n_shape, n_exp), stream);
 }
 
 static int device_cu_count() {
@@ -626,6 +517,9 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
                      int n_exp, float im_size, float* vertex_proj, hipStream_t stream) {
     using namespace fr;
     if (B == 0 || N == 0) return FR_OK;
+    if (fr_decode_arith_get() == FR_DECODE_ARITH_Q30 && fr_decode_q_supported(n_shape, n_exp))
+        return fr_launch_decode_q(params, reinterpret_cast<const char*>(packed) + packed_q_offset(N, n_shape, n_exp),
+                                  R_override, B, N, n_shape, n_exp, im_size, vertex_proj, device_cu_count(), stream);
     size_t tiles = (size_t)tiles_of(N);
     size_t G = (size_t)groups_of(n_shape) + groups_of(n_exp);
     size_t lds = G * KGROUP * 16 * sizeof(float4) + 64 * 12 * sizeof(float) + 64 * 3 * 2 * sizeof(double);

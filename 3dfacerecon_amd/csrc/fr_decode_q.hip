@@ -1,0 +1,426 @@
+// 3DMM decode for gfx950, Q30 arithmetic: the basis blend  [3N x (ns+ne)] . [(ns+ne) x B]  of network.py:153-159 as an
+// EXACT fixed-point dot product on the int8 matrix cores (v_mfma_i32_16x16x64_i8, 32x the rate of the f32-input MFMA),
+// rounded to fp32 once.
+//
+// Why: the exact-f32 MFMA (fr_decode.hip) runs at the fp32 VECTOR rate -- 30 us of matrix pipe per 64 faces -- while the
+// 153 MB basis needs ~25 us of HBM.  Integer arithmetic is the only other arithmetic that is order-independent and hence
+// exactly re-statable on a CPU (the bf16/fp8 MFMAs accumulate in an unspecified internal order), and the int8 cores give
+// 16 digit products in the time of one f32 step, which is enough for 31-bit operands:
+//   qA[r,k] = rint(A[r,k] 2^(30 - re_r - ce_k))   (per-row and per-column power-of-two scales; |qA| <= 2^30)
+//   qB[k,b] = rint(x[b,k] 2^(30 - be_b + ce_k))
+//   v[r,b]  = fl32( mu_r + (sum_k qA qB) 2^(re_r + be_b - 60) )
+// with qA, qB split into four balanced base-256 digits each and all 16 digit products accumulated in int32 by the MFMA.
+// Entries within 2^-6 of their row's maximum are represented exactly; the quantisation error of the rest is below
+// 2^-31 of the row / column maximum, so the result is the correctly rounded fp32 value of the real-number blend in
+// 99.7 % of the cases on the model's data (mean error 0.25 ulp against the f32 chain's 0.5; tests/test_decode_q30_*.py).
+// The specification is restated in oracle/fr_oracle.c ("Q30 decode") and the kernel is held to it BIT FOR BIT.
+//
+// Packed image (built once by fr_decode_pack_basis, after the f32 image): int ce[S*64] | per 16-vertex tile:
+//   fragment (c, sidx, i): coordinate c, k-step s = (sidx == 0 ? S-1 : sidx-1), digit i; lane l holds 16 bytes:
+//   row 16*tile + (l & 15), k = 64 s + 16 (l >> 4) + t.  Only the KB = ceil(K/16) live 16-k groups are stored, so the
+//   LAST k-step's fragments are short (256 * (KB - 4 (S-1)) bytes) -- they come FIRST in a coordinate, the lanes past
+//   their end read the bytes that follow (harmless: the matching parameter digits are zero), and the 256 bytes that
+//   follow the very first fragment of a tile are its payload: per row {mu_x, mu_y, mu_z, -re_x | -re_y << 10 | -re_z << 20}.
+//   With KB % 4 != 0 the payload therefore arrives in lanes 48..63 of the tile's first fragment load, free of charge.
+#include "fr_decode_shared.h"
+
+namespace fr {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct QShape {
+    int K, KB, S, ngl;           // coefficients, live 16-k groups, k-steps of 64, groups in the last k-step
+    size_t coord_bytes, tile_bytes, hdr_bytes;
+};
+__host__ __device__ inline QShape q_shape(int ns, int ne) {
+    QShape q;
+    q.K = ns + ne;
+    q.KB = (q.K + 15) / 16;
+    if (q.KB == 0) q.KB = 1;
+    q.S = (q.KB + 3) / 4;
+    q.ngl = q.KB - 4 * (q.S - 1);
+    q.coord_bytes = (size_t)1024 * q.KB;
+    q.tile_bytes = 3 * q.coord_bytes + 256;
+    q.hdr_bytes = ((size_t)q.S * 64 * sizeof(int) + 255) & ~(size_t)255;
+    return q;
+}
+// byte offset of fragment (c, sidx, i) inside a tile
+__host__ __device__ inline size_t q_frag_off(const QShape& q, int c, int sidx, int i) {
+    size_t o = (size_t)c * q.coord_bytes;
+    o += sidx == 0 ? (size_t)i * 256 * q.ngl : (size_t)4 * 256 * q.ngl + (size_t)(sidx - 1) * 4096 + (size_t)i * 1024;
+    return o + ((c | sidx | i) ? 256 : 0);
+}
+
+__device__ __forceinline__ int q_exp_of(double x) {  // frexp exponent: x = m 2^e, 0.5 <= |m| < 1
+    int e;
+    (void)frexp(x, &e);
+    return e;
+}
+__device__ __forceinline__ int q_digit(int q, int i) {  // balanced base-256 digit i (0 = most significant) of q
+    int d3 = ((q + 128) & 255) - 128;
+    q = (q - d3) >> 8;
+    int d2 = ((q + 128) & 255) - 128;
+    q = (q - d2) >> 8;
+    int d1 = ((q + 128) & 255) - 128;
+    q = (q - d1) >> 8;
+    return i == 0 ? q : i == 1 ? d1 : i == 2 ? d2 : d3;
+}
+
+// ---- pack -------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float q_basis(const float* pc_shape, const float* pc_exp, size_t row, int k, int ns, int ne) {
+    return k < ns ? pc_shape[row * ns + k] : pc_exp[row * ne + (k - ns)];
+}
+// column maxima (bit patterns of |a|, finite entries only): one thread per column walks a chunk of rows
+__global__ __launch_bounds__(256) void q_colmax_kernel(const float* __restrict__ pc_shape, const float* __restrict__ pc_exp,
+                                                       int N, int ns, int ne, unsigned* __restrict__ colmax) {
+    const int K = ns + ne;
+    const size_t rows = (size_t)3 * N;
+    const size_t chunk = (rows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        unsigned m = 0;
+        for (size_t r = r0; r < r1; r++) {
+            const unsigned u = __float_as_uint(q_basis(pc_shape, pc_exp, r, k, ns, ne)) & 0x7FFFFFFFu;
+            if (u < 0x7F800000u && u > m) m = u;
+        }
+        if (m) atomicMax(&colmax[k], m);
+    }
+}
+__global__ void q_ce_kernel(const unsigned* __restrict__ colmax, int K, int KP, int* __restrict__ ce) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= KP) return;
+    const unsigned m = k < K ? colmax[k] : 0u;
+    ce[k] = m ? q_exp_of((double)__uint_as_float(m)) : 0;
+}
+// per-vertex payload: mu and the three row exponents
+__global__ __launch_bounds__(256) void q_payload_kernel(const float* __restrict__ mu, const float* __restrict__ pc_shape,
+                                                        const float* __restrict__ pc_exp, int N, int ns, int ne,
+                                                        const int* __restrict__ ce, char* __restrict__ tiles_base,
+                                                        QShape qs) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long NP = (long long)tiles_of(N) * TILE_V;
+    if (p >= NP) return;
+    float m3[3] = {0.f, 0.f, 0.f};
+    unsigned ex = 0;
+    if (p < N) {
+        for (int c = 0; c < 3; c++) {
+            const size_t row = (size_t)c * N + p;
+            m3[c] = mu[row];
+            int re = INT_MIN;
+            bool bad = false;
+            for (int k = 0; k < qs.K; k++) {
+                const float a = q_basis(pc_shape, pc_exp, row, k, ns, ne);
+                if (!isfinite(a)) bad = true;
+                else if (a != 0.f) re = max(re, q_exp_of((double)a) - ce[k]);
+            }
+            if (re == INT_MIN) re = 0;
+            const unsigned e10 = bad ? 1023u : (unsigned)min(1022, max(0, -re));   // re <= 0 by construction
+            ex |= e10 << (10 * c);
+        }
+    }
+    uint4 w;
+    w.x = __float_as_uint(m3[0]);
+    w.y = __float_as_uint(m3[1]);
+    w.z = __float_as_uint(m3[2]);
+    w.w = ex;
+    char* tb = tiles_base + (size_t)(p / TILE_V) * qs.tile_bytes;
+    *reinterpret_cast<uint4*>(tb + (size_t)256 * qs.ngl + (size_t)(p % TILE_V) * 16) = w;
+}
+// digit fragments: one thread per (tile, c, sidx, i, lane)
+__global__ __launch_bounds__(256) void q_pack_kernel(const float* __restrict__ pc_shape, const float* __restrict__ pc_exp,
+                                                     int N, int ns, int ne, const int* __restrict__ ce,
+                                                     char* __restrict__ tiles_base, QShape qs) {
+    const long long per_tile = (long long)3 * qs.S * 4 * 64;
+    const long long total = (long long)tiles_of(N) * per_tile;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += step) {
+        const int lane = (int)(it & 63);
+        long long r = it >> 6;
+        const int i = (int)(r & 3);
+        r >>= 2;
+        const int sidx = (int)(r % qs.S);
+        r /= qs.S;
+        const int c = (int)(r % 3);
+        const long long tile = r / 3;
+        const int s = sidx == 0 ? qs.S - 1 : sidx - 1;
+        const int g = lane >> 4;
+        if (sidx == 0 && g >= qs.ngl) continue;   // not stored
+        char* tb = tiles_base + (size_t)tile * qs.tile_bytes;
+        const long long p = tile * TILE_V + (lane & 15);
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        if (p < N) {
+            const uint4 pay = *reinterpret_cast<const uint4*>(tb + (size_t)256 * qs.ngl + (size_t)(lane & 15) * 16);
+            const unsigned e10 = (pay.w >> (10 * c)) & 1023u;
+            const int re = -(int)e10;   // (a flagged row: its digits are irrelevant, the epilogue writes NaN)
+            const size_t row = (size_t)c * N + p;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int k = 64 * s + 16 * g + t;
+                int d = 0;
+                if (k < qs.K) {
+                    const float a = q_basis(pc_shape, pc_exp, row, k, ns, ne);
+                    if (isfinite(a) && e10 != 1023u) d = q_digit((int)rint(ldexp((double)a, 30 - re - ce[k])), i);
+                }
+                w[t >> 2] |= (unsigned)(d & 255) << (8 * (t & 3));
+            }
+        }
+        *reinterpret_cast<uint4*>(tb + q_frag_off(qs, c, sidx, i) + (size_t)lane * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---- decode -----------------------------------------------------------------------------------------------------------
+struct DecodeQArgs {
+    DecodeArgs d;          // params, R_override, out, B, N, ns, ne, b0, im_size (A / mu_p / halves unused)
+    const char* tiles;     // first tile of the Q image
+    const int* ce;         // column exponents [S*64]
+    QShape qs;
+};
+
+constexpr int Q_BE_BAD = 0x7FFFFFFF;
+
+// Parameters -> LDS as digit fragments (B operand).  Image: [(s*4 + j)*4 + nb][lane] x 16 bytes; lane l of column block
+// nb holds column 16 nb + (l & 15), k = 64 s + 16 (l >> 4) + t.  be_s[b] = the column's exponent (Q_BE_BAD: a
+// non-finite parameter).  Ends with a barrier.
+template <int DEC_BLOCK>
+__device__ __forceinline__ void q_stage_params(const DecodeQArgs& a, char* Bimg, int* be_s, int tid, int nd, int nbatch) {
+    const int K = a.qs.K, S = a.qs.S;
+    for (int b = tid; b < MAXB; b += DEC_BLOCK) be_s[b] = INT_MIN;
+    __syncthreads();
+    const int items = MAXB * 4 * S;
+    for (int it = tid; it < items; it += DEC_BLOCK) {
+        const int b = it & 63, u = it >> 6;
+        if (b >= nbatch || 16 * u >= K) continue;
+        const float* prow = a.d.params + (size_t)(a.d.b0 + b) * nd + FR_N_POSE;
+        int e = INT_MIN;
+        bool bad = false;
+#pragma unroll 4
+        for (int t = 0; t < 16; t++) {
+            const int k = 16 * u + t;
+            if (k < K) {
+                const float x = prow[k];
+                if (!isfinite(x)) bad = true;
+                else if (x != 0.f) e = max(e, q_exp_of((double)x) + a.ce[k]);
+            }
+        }
+        if (bad) atomicMax(&be_s[b], Q_BE_BAD);
+        else if (e != INT_MIN) atomicMax(&be_s[b], e);
+    }
+    __syncthreads();
+    for (int it = tid; it < items; it += DEC_BLOCK) {
+        const int b = it & 63, u = it >> 6;
+        const int s = u >> 2, g = u & 3;
+        unsigned w[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[j][q] = 0u;
+        int be = b < nbatch ? be_s[b] : 0;
+        if (be == INT_MIN) be = 0;
+        if (b < nbatch && be != Q_BE_BAD && 16 * u < K) {
+            const float* prow = a.d.params + (size_t)(a.d.b0 + b) * nd + FR_N_POSE;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int k = 16 * u + t;
+                if (k < K) {
+                    const int q = (int)rint(ldexp((double)prow[k], a.ce[k] + 30 - be));
+                    int d3 = ((q + 128) & 255) - 128;
+                    int q1 = (q - d3) >> 8;
+                    int d2 = ((q1 + 128) & 255) - 128;
+                    q1 = (q1 - d2) >> 8;
+                    int d1 = ((q1 + 128) & 255) - 128;
+                    q1 = (q1 - d1) >> 8;
+                    const int sh = 8 * (t & 3);
+                    w[0][t >> 2] |= (unsigned)(q1 & 255) << sh;
+                    w[1][t >> 2] |= (unsigned)(d1 & 255) << sh;
+                    w[2][t >> 2] |= (unsigned)(d2 & 255) << sh;
+                    w[3][t >> 2] |= (unsigned)(d3 & 255) << sh;
+                }
+            }
+        }
+        const int nb = b >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<uint4*>(Bimg + ((size_t)((s * 4 + j) * 4 + nb) * 64 + g * 16 + (b & 15)) * 16) =
+                make_uint4(w[j][0], w[j][1], w[j][2], w[j][3]);
+    }
+    __syncthreads();
+    for (int b = tid; b < MAXB; b += DEC_BLOCK)
+        if (be_s[b] == INT_MIN) be_s[b] = 0;
+    // (the caller's pose_prologue barriers publish be_s)
+}
+
+// One coordinate's seven level sums -> fl32(mu + I 2^(re + be - 60)) for this lane's 4 rows x NBW columns.
+template <int NBW>
+__device__ __forceinline__ void q_finish(const i32x4 (&acc)[7][NBW], const float (&mu4)[4], const int (&e4)[4],
+                                         const int (&be)[NBW], f32x4 (&out)[NBW]) {
+#pragma unroll
+    for (int nb = 0; nb < NBW; nb++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double h = (double)acc[0][nb][r];
+#pragma unroll
+            for (int s = 1; s < 7; s++) h = __builtin_fma(h, 256.0, (double)acc[s][nb][r]);
+            const bool bad = e4[r] == 1023 || be[nb] == Q_BE_BAD;
+            const int e = bad ? 0 : be[nb] - e4[r] - 60;
+            const double sc = __longlong_as_double((long long)(1023 + e) << 52);
+            const double d = (double)mu4[r] + h * sc;
+            out[nb][r] = bad ? __uint_as_float(0x7FC00000u) : (float)d;
+        }
+    }
+}
+
+// Generic kernel (any basis shape with ns + ne <= 512): one wave per 16-vertex tile, NBW column blocks, plain loads.
+template <int NBW, int DEC_WAVES>
+__global__ __launch_bounds__(DEC_WAVES * 64) void decode_q_kernel(DecodeQArgs a) {
+    constexpr int DEC_BLOCK = DEC_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) char qsmem[];
+    const QShape qs = a.qs;
+    char* Bimg = qsmem;                                                   // S * 16 KiB
+    float* Mt = reinterpret_cast<float*>(Bimg + (size_t)qs.S * 16384);     // [64][12]
+    double* SC = reinterpret_cast<double*>(Mt + MAXB * 12);                // [64][3][2]
+    int* be_s = reinterpret_cast<int*>(SC + MAXB * 6);                     // [64]
+    const int tid = threadIdx.x;
+    const int nd = FR_N_POSE + a.d.ns + a.d.ne;
+    const int nbatch = min(a.d.B - a.d.b0, MAXB);
+    q_stage_params<DEC_BLOCK>(a, Bimg, be_s, tid, nd, nbatch);
+    pose_prologue<MAXB>(a.d, Mt, SC, tid, nd, nbatch);
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int tiles = tiles_of(a.d.N);
+    int be[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; nb++) be[nb] = be_s[16 * nb + (lane & 15)];
+    for (int tile = (int)blockIdx.x * DEC_WAVES + wave; tile < tiles; tile += (int)gridDim.x * DEC_WAVES) {
+        const char* tb = a.tiles + (size_t)tile * qs.tile_bytes;
+        uint4 pay[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            pay[r] = *reinterpret_cast<const uint4*>(tb + (size_t)256 * qs.ngl + (size_t)(4 * (lane >> 4) + r) * 16);
+        f32x4 v[3][NBW];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            i32x4 acc[7][NBW];
+#pragma unroll
+            for (int s = 0; s < 7; s++)
+#pragma unroll
+                for (int nb = 0; nb < NBW; nb++) acc[s][nb] = (i32x4){0, 0, 0, 0};
+            for (int sidx = 0; sidx < qs.S; sidx++) {
+                const int s = sidx == 0 ? qs.S - 1 : sidx - 1;
+                i32x4 af[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    af[i] = *reinterpret_cast<const i32x4*>(tb + q_frag_off(qs, c, sidx, i) + (size_t)lane * 16);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    i32x4 bf[NBW];
+#pragma unroll
+                    for (int nb = 0; nb < NBW; nb++)
+                        bf[nb] = *reinterpret_cast<const i32x4*>(Bimg + ((size_t)((s * 4 + j) * 4 + nb) * 64 + lane) * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int nb = 0; nb < NBW; nb++)
+                            acc[i + j][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[nb], acc[i + j][nb], 0, 0, 0);
+                }
+            }
+            float mu4[4];
+            int e4[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                mu4[r] = __uint_as_float(c == 0 ? pay[r].x : c == 1 ? pay[r].y : pay[r].z);
+                e4[r] = (int)((pay[r].w >> (10 * c)) & 1023u);
+            }
+            q_finish<NBW>(acc, mu4, e4, be, v[c]);
+        }
+        decode_store<NBW>(a.d, v[0], v[1], v[2], Mt, tile, 0, lane, nbatch, a.d.N);
+    }
+}
+
+}  // namespace fr
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+size_t fr_packed_q_bytes(int N, int n_shape, int n_exp) {
+    using namespace fr;
+    const QShape qs = q_shape(n_shape, n_exp);
+    return qs.hdr_bytes + (size_t)tiles_of(N) * qs.tile_bytes + 1024;   // + slack: the last short fragment's over-read
+}
+
+static unsigned* q_colmax_scratch(int K) {  // per-device scratch for the column maxima (pack is a one-time operation)
+    static unsigned* buf[64];
+    static int cap[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (cap[dev] < K) {
+        if (buf[dev]) (void)hipFree(buf[dev]);
+        buf[dev] = nullptr;
+        cap[dev] = 0;
+        if (hipMalloc(&buf[dev], sizeof(unsigned) * (size_t)(K + 64)) != hipSuccess) return nullptr;
+        cap[dev] = K + 64;
+    }
+    return buf[dev];
+}
+
+int fr_launch_pack_q(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
+                     void* qimage, hipStream_t stream) {
+    using namespace fr;
+    if (N == 0) return FR_OK;
+    const QShape qs = q_shape(n_shape, n_exp);
+    if (qs.K > 512) return FR_OK;   // the Q30 kernels do not take this shape; the f32 image serves it
+    int* ce = reinterpret_cast<int*>(qimage);
+    char* tb = reinterpret_cast<char*>(qimage) + qs.hdr_bytes;
+    const int KP = qs.S * 64;
+    unsigned* colmax = q_colmax_scratch(KP);
+    if (!colmax) return FR_ERR_LAUNCH;
+    if (hipMemsetAsync(colmax, 0, sizeof(unsigned) * KP, stream) != hipSuccess) return FR_ERR_LAUNCH;
+    if (hipMemsetAsync(qimage, 0, fr_packed_q_bytes(N, n_shape, n_exp), stream) != hipSuccess) return FR_ERR_LAUNCH;
+    if (qs.K > 0)
+        hipLaunchKernelGGL(q_colmax_kernel, dim3(1024), dim3(256), 0, stream, pc_shape, pc_exp, N, n_shape, n_exp, colmax);
+    hipLaunchKernelGGL(q_ce_kernel, dim3((KP + 255) / 256), dim3(256), 0, stream, colmax, qs.K, KP, ce);
+    const long long NP = (long long)tiles_of(N) * TILE_V;
+    hipLaunchKernelGGL(q_payload_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, mu, pc_shape, pc_exp, N,
+                       n_shape, n_exp, ce, tb, qs);
+    hipLaunchKernelGGL(q_pack_kernel, dim3(4096), dim3(256), 0, stream, pc_shape, pc_exp, N, n_shape, n_exp, ce, tb, qs);
+    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
+}
+
+bool fr_decode_q_supported(int n_shape, int n_exp) { return n_shape + n_exp <= 512; }
+
+template <int NBW>
+static int launch_q_generic(const fr::DecodeQArgs& a, size_t lds, int cus, hipStream_t stream) {
+    static unsigned char lds_ok[64];
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_q_kernel<NBW, 8>), lds_ok) != hipSuccess)
+        return FR_ERR_LAUNCH;
+    const int tiles = fr::tiles_of(a.d.N);
+    const int grid = (int)min((long long)cus, (long long)(tiles + 7) / 8);
+    hipLaunchKernelGGL((fr::decode_q_kernel<NBW, 8>), dim3(grid), dim3(512), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
+}
+
+int fr_launch_decode_q(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
+                       int n_exp, float im_size, float* vertex_proj, int cus, hipStream_t stream) {
+    using namespace fr;
+    if (B == 0 || N == 0) return FR_OK;
+    DecodeQArgs a;
+    a.qs = q_shape(n_shape, n_exp);
+    a.ce = reinterpret_cast<const int*>(qimage);
+    a.tiles = reinterpret_cast<const char*>(qimage) + a.qs.hdr_bytes;
+    a.d.params = params;
+    a.d.A = nullptr;
+    a.d.mu_p = nullptr;
+    a.d.R_override = R_override;
+    a.d.out = vertex_proj;
+    a.d.B = B; a.d.N = N; a.d.ns = n_shape; a.d.ne = n_exp;
+    a.d.halves = 1;
+    a.d.im_size = im_size;
+    const size_t lds = (size_t)a.qs.S * 16384 + MAXB * 12 * sizeof(float) + MAXB * 6 * sizeof(double) + MAXB * sizeof(int);
+    if (lds > 160 * 1024) return FR_ERR_UNSUPPORTED;
+    for (int b0 = 0; b0 < B; b0 += MAXB) {
+        a.d.b0 = b0;
+        const int nbt = (min(B - b0, MAXB) + 15) / 16;
+        int rc = nbt == 1 ? launch_q_generic<1>(a, lds, cus, stream)
+                 : nbt == 2 ? launch_q_generic<2>(a, lds, cus, stream)
+                            : launch_q_generic<4>(a, lds, cus, stream);
+        if (rc != FR_OK) return rc;
+    }
+    return FR_OK;
+}

@@ -1,0 +1,152 @@
+// Pieces shared by the two decode arithmetic paths (fr_decode.hip: exact-f32 MFMA chain; fr_decode_q.hip: Q30 fixed
+// point on the int8 MFMA): argument block, in-kernel float64 rotation, work distribution, pose prologue, fused epilogue.
+#pragma once
+#include "fr_common.h"
+
+namespace fr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int TILE_V = 16;      // vertices per wave tile (MFMA M)
+constexpr int MAXB = 64;        // batch columns per pass (4 MFMA column blocks of 16)
+__host__ __device__ inline int tiles_of(int N) { return (N + TILE_V - 1) / TILE_V; }
+
+struct DecodeArgs {
+    const float* params;      // [B, 7+ns+ne]
+    const float4* A;          // packed basis
+    const float* mu_p;        // packed mu
+    const float* R_override;  // [B,9] or null
+    float* out;               // [B,3,N]
+    int B, N, ns, ne;
+    int b0;                   // first batch column of this pass
+    int halves;               // column-block groups per tile: a work item is (tile, half)
+    float im_size;
+};
+
+// rotation in float64 exactly as network.py:276-290: R = (R_pitch . R_yaw) . R_roll, 3-term dots, no FMA.
+__device__ __forceinline__ void mat3_mul(const double* A, const double* Bm, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            C[3 * i + j] = (A[3 * i + 0] * Bm[0 + j] + A[3 * i + 1] * Bm[3 + j]) + A[3 * i + 2] * Bm[6 + j];
+}
+__device__ __forceinline__ void rotation_from_sincos(double sp, double cp, double sy, double cy, double st, double ct,
+                                                     float* R9) {
+    double Rp[9] = {1, 0, 0, 0, cp, sp, 0, -sp, cp};
+    double Ry[9] = {cy, 0, -sy, 0, 1, 0, sy, 0, cy};
+    double Rr[9] = {ct, st, 0, -st, ct, 0, 0, 0, 1};
+    double PY[9], Rm[9];
+    mat3_mul(Rp, Ry, PY);
+    mat3_mul(PY, Rr, Rm);
+#pragma unroll
+    for (int i = 0; i < 9; i++) R9[i] = (float)Rm[i];
+}
+
+// Work distribution shared by the decode kernels.  A workgroup works on `slots` tiles at a time (slot = wave / halves).
+// Tiles are dealt in adjacent PAIRS: slots 2s and 2s+1 of a workgroup take tiles 2P and 2P+1, so the two 64-byte pieces
+// a pair writes into each output row come from one CU at about the same time; pair P goes to workgroup perm(P % grid) of
+// round P / grid, where perm keeps consecutive pairs on the same XCD (workgroup b runs on XCD b % 8), so the partial
+// cache lines at the seams still meet in one L2.  Dealing pairs round-robin keeps the last, partial round to at most one
+// extra pair per CU.
+struct TileWalk {
+    int first, stride;
+};
+__device__ __forceinline__ TileWalk tile_walk(int slot, int slots, int b, int grid) {
+    const int pb = (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b;
+    TileWalk w;
+    if (slots & 1) {  // odd slot count (not used by the launchers): plain round-robin over tiles
+        w.first = slot * grid + pb;
+        w.stride = slots * grid;
+    } else {
+        w.first = 2 * ((slot >> 1) * grid + pb) + (slot & 1);
+        w.stride = slots * grid;  // = 2 * (slots / 2) * grid
+    }
+    return w;
+}
+
+// Pose part of the per-CU prologue: Mt[b] = f.R | t3d for the pass's MB columns (float64 rotation, network.py:266-297).
+// Needs >= 3*MB threads; ends with a workgroup barrier (so it also publishes whatever the caller staged before it).
+template <int MB>
+__device__ __forceinline__ void pose_prologue(const DecodeArgs& a, float* Mt, double* SC, int tid, int nd, int nbatch) {
+    // pose: the 3*MB float64 sincos evaluations are spread over 3*MB threads, then MB threads assemble f*R and t
+    if (tid < 3 * MB && !a.R_override) {
+        const int b = tid / 3, ang = tid - 3 * b;
+        double sn = 0.0, cs = 1.0;
+        if (b < nbatch) sincos((double)a.params[(size_t)(a.b0 + b) * nd + ang], &sn, &cs);
+        SC[(b * 3 + ang) * 2 + 0] = sn;
+        SC[(b * 3 + ang) * 2 + 1] = cs;
+    }
+    __syncthreads();
+    if (tid < MB) {
+        float m[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) m[i] = 0.f;
+        if (tid < nbatch) {
+            const float* pr = a.params + (size_t)(a.b0 + tid) * nd;
+            float R[9];
+            if (a.R_override) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) R[i] = a.R_override[(size_t)(a.b0 + tid) * 9 + i];
+            } else {
+                const double* sc = SC + tid * 6;
+                rotation_from_sincos(sc[0], sc[1], sc[2], sc[3], sc[4], sc[5], R);
+            }
+            float f = pr[6];
+#pragma unroll
+            for (int i = 0; i < 9; i++) m[i] = f * R[i];  // f (.) R elementwise, network.py:163-165
+            m[9] = pr[3];
+            m[10] = pr[4];
+            m[11] = pr[5];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) Mt[tid * 12 + i] = m[i];
+    }
+    __syncthreads();
+
+}
+
+// Fused epilogue of one work item: 3x3 (f.R) transform, +t3d, y flip, store [B,3,N].
+template <int NBW>
+__device__ __forceinline__ void decode_store(const DecodeArgs& a, const f32x4 (&s0)[NBW], const f32x4 (&s1)[NBW],
+                                             const f32x4 (&s2)[NBW], const float* Mt, int tile, int hf, int lane,
+                                             int nbatch, int N) {
+    const int p0v = tile * TILE_V + 4 * (lane >> 4);  // first of this lane's 4 vertices
+#pragma unroll
+    for (int nb = 0; nb < NBW; nb++) {
+        const int bb = 16 * (hf * NBW + nb) + (lane & 15);
+        if (bb >= nbatch) continue;
+        const float* m = Mt + bb * 12;
+        f32x4 px, py, pz;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float vx = s0[nb][r], vy = s1[nb][r], vz = s2[nb][r];
+            const float qx = __builtin_fmaf(m[2], vz, __builtin_fmaf(m[1], vy, m[0] * vx)) + m[9];
+            const float qy = __builtin_fmaf(m[5], vz, __builtin_fmaf(m[4], vy, m[3] * vx)) + m[10];
+            const float qz = __builtin_fmaf(m[8], vz, __builtin_fmaf(m[7], vy, m[6] * vx)) + m[11];
+            px[r] = qx;
+            py[r] = (a.im_size - qy) - 1.0f;  // network.py:168
+            pz[r] = qz;
+        }
+        float* ox = a.out + ((size_t)(a.b0 + bb) * 3) * N + p0v;
+        float* oy = ox + N;
+        float* oz = oy + N;
+        if (p0v + 3 < N) {
+            *reinterpret_cast<f32x4u*>(ox) = px;
+            *reinterpret_cast<f32x4u*>(oy) = py;
+            *reinterpret_cast<f32x4u*>(oz) = pz;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (p0v + r < N) {
+                    ox[r] = px[r];
+                    oy[r] = py[r];
+                    oz[r] = pz[r];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace fr

@@ -474,3 +474,127 @@ int fr_oracle_decode_3dmm_backward_f64(const float* grad_vertex_proj, const floa
     free(dv);
     return 0;
 }
+
+/* ---- Q30 decode: the exact specification of the product's fixed-point basis blend ---------------------------------
+ * NOT the reference's arithmetic (the reference runs two fp32 tf.matmuls whose summation order is unknowable,
+ * nets/network.py:153-156): this is the written spec of the gfx950 int8-MFMA decode, restated here so that the HIP
+ * kernel can be held to it bit for bit, and so that its distance from the fp32 spec above and from the float64
+ * evaluation can be measured on the CPU (tests/test_decode_q30_cpu.py).  Everything is integer or exactly specified
+ * float64 arithmetic, hence order-independent:
+ *   A = [pc_shape | pc_exp]  (3N x K),  x = [alpha | beta]  (K)
+ *   ce_k  = frexp exponent of max_r |A[r,k]|           (0 for an all-zero column)      -> A'[r,k] = A[r,k] 2^-ce_k, |A'| < 1
+ *   re_r  = frexp exponent of max_k |A'[r,k]|          (0 for an all-zero row; <= 0)
+ *   qA    = rint(A'[r,k] 2^(30-re_r))                  (|qA| <= 2^30; entries within 2^-6 of the row maximum are exact)
+ *   be    = max_k (frexp exponent of x_k) + ce_k       (0 if x == 0)                   -> x'_k = x_k 2^ce_k
+ *   qB    = rint(x'_k 2^(30-be))
+ *   I     = sum_k qA qB   evaluated as seven level sums L_s = sum_k sum_{i+j=s} a_i b_j over the balanced base-256
+ *           digits of qA, qB (most significant first), combined as h = fl64(h*256 + L_s), s = 0..6 -- exact whenever
+ *           |I| < 2^53, correctly rounded steps otherwise
+ *   v_r   = fl32( fl64( mu_r + h 2^(re_r+be-60) ) )    -- ONE rounding of mu + S + E instead of the chain's ~K
+ *   then the pose product and y flip exactly as fr_decode_body.
+ * A non-finite parameter makes the face's vertices NaN, a non-finite basis entry its row's. */
+static int fr_q30_exp(double x) { int e; frexp(x, &e); return e; }
+static void fr_q30_digits(int32_t q, int d[4]) {
+    for (int t = 3; t > 0; t--) {
+        int l = ((q + 128) & 255) - 128;
+        d[t] = l;
+        q = (q - l) >> 8;
+    }
+    d[0] = q;
+}
+int fr_oracle_decode_3dmm_q30(const float* params, const float* mu, const float* pc_shape, const float* pc_exp,
+                              const float* R_override, int B, int N, int ns, int ne, float im_size,
+                              float* vertex_proj) {
+    if (B < 0 || N < 0 || ns < 0 || ne < 0) return -1;
+    const int K = ns + ne, nd = 7 + K;
+    const size_t rows = (size_t)3 * N;
+    int* ce = (int*)calloc(K > 0 ? K : 1, sizeof(int));
+    int32_t* qB = (int32_t*)calloc((size_t)(B > 0 ? B : 1) * (K > 0 ? K : 1), sizeof(int32_t));
+    int32_t* qA = (int32_t*)calloc(K > 0 ? K : 1, sizeof(int32_t));
+    int* be = (int*)calloc(B > 0 ? B : 1, sizeof(int));
+    char* badb = (char*)calloc(B > 0 ? B : 1, 1);
+    float* v = (float*)malloc(sizeof(float) * 3 * (size_t)(B > 0 ? B : 1));
+    if (!ce || !qB || !qA || !be || !badb || !v) return -2;
+#define FR_A(r, k) ((k) < ns ? pc_shape[(r) * ns + (k)] : pc_exp[(r) * ne + ((k) - ns)])
+    for (int k = 0; k < K; k++) {
+        float m = 0.0f;
+        for (size_t r = 0; r < rows; r++) {
+            float a = fabsf(FR_A(r, k));
+            if (isfinite(a) && a > m) m = a;
+        }
+        ce[k] = m > 0.0f ? fr_q30_exp((double)m) : 0;
+    }
+    for (int b = 0; b < B; b++) {
+        const float* x = params + (size_t)b * nd + 7;
+        int e = INT_MIN;
+        for (int k = 0; k < K; k++) {
+            if (!isfinite(x[k])) badb[b] = 1;
+            else if (x[k] != 0.0f) { int ek = fr_q30_exp((double)x[k]) + ce[k]; if (ek > e) e = ek; }
+        }
+        be[b] = e == INT_MIN ? 0 : e;
+        for (int k = 0; k < K; k++)
+            qB[(size_t)b * K + k] = isfinite(x[k]) ? (int32_t)rint(ldexp((double)x[k], ce[k] + 30 - be[b])) : 0;
+    }
+    float* Ms = (float*)malloc(sizeof(float) * 9 * (size_t)(B > 0 ? B : 1));
+    if (!Ms) return -2;
+    for (int b = 0; b < B; b++) {
+        const float* pr = params + (size_t)b * nd;
+        float R[9];
+        if (R_override) memcpy(R, R_override + 9 * (size_t)b, sizeof(R));
+        else fr_oracle_rotation_matrix(pr[0], pr[1], pr[2], R);
+        for (int i = 0; i < 9; i++) Ms[9 * (size_t)b + i] = pr[6] * R[i];
+    }
+    for (int p = 0; p < N; p++) {
+        for (int c = 0; c < 3; c++) {
+            const size_t r = (size_t)c * N + p;
+            int re = INT_MIN, badr = 0;
+            for (int k = 0; k < K; k++) {
+                float a = FR_A(r, k);
+                if (!isfinite(a)) badr = 1;
+                else if (a != 0.0f) { int ek = fr_q30_exp((double)a) - ce[k]; if (ek > re) re = ek; }
+            }
+            if (re == INT_MIN) re = 0;
+            for (int k = 0; k < K; k++) {
+                float a = FR_A(r, k);
+                qA[k] = isfinite(a) ? (int32_t)rint(ldexp((double)a, 30 - re - ce[k])) : 0;
+            }
+            for (int b = 0; b < B; b++) {
+                const int32_t* qb = qB + (size_t)b * K;
+                __int128 I = 0;
+                for (int k = 0; k < K; k++) I += (__int128)((int64_t)qA[k] * (int64_t)qb[k]);
+                double h;
+                const __int128 lim = (__int128)1 << 52;
+                if (I < lim && I > -lim) {
+                    h = (double)(int64_t)I;   /* every partial of the level chain is exact: h == I */
+                } else {                       /* the chain's own roundings, level by level */
+                    int64_t L[7] = {0, 0, 0, 0, 0, 0, 0};
+                    for (int k = 0; k < K; k++) {
+                        int da[4], db[4];
+                        fr_q30_digits(qA[k], da);
+                        fr_q30_digits(qb[k], db);
+                        for (int i = 0; i < 4; i++)
+                            for (int j = 0; j < 4; j++) L[i + j] += (int64_t)da[i] * db[j];
+                    }
+                    h = (double)L[0];
+                    for (int s = 1; s < 7; s++) h = h * 256.0 + (double)L[s];
+                }
+                double d = (double)mu[r] + ldexp(h, re + be[b] - 60);
+                v[(size_t)b * 3 + c] = (badr || badb[b]) ? NAN : (float)d;
+            }
+        }
+        for (int b = 0; b < B; b++) {
+            const float* pr = params + (size_t)b * nd;
+            const float* M = Ms + 9 * (size_t)b;
+            const float vx = v[(size_t)b * 3], vy = v[(size_t)b * 3 + 1], vz = v[(size_t)b * 3 + 2];
+            float px = fmaf(M[2], vz, fmaf(M[1], vy, M[0] * vx)) + pr[3];
+            float py = fmaf(M[5], vz, fmaf(M[4], vy, M[3] * vx)) + pr[4];
+            float pz = fmaf(M[8], vz, fmaf(M[7], vy, M[6] * vx)) + pr[5];
+            vertex_proj[((size_t)b * 3 + 0) * N + p] = px;
+            vertex_proj[((size_t)b * 3 + 1) * N + p] = (im_size - py) - 1.0f;
+            vertex_proj[((size_t)b * 3 + 2) * N + p] = pz;
+        }
+    }
+#undef FR_A
+    free(ce); free(qB); free(qA); free(be); free(badb); free(v); free(Ms);
+    return 0;
+}

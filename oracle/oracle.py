@@ -54,7 +54,7 @@ def lib():
         L.fr_oracle_zbuffer.restype = ctypes.c_int
         L.fr_oracle_rotation_matrix.argtypes = [ctypes.c_float] * 3 + [_f32p]
         L.fr_oracle_rotation_matrix.restype = None
-        for name in ("fr_oracle_decode_3dmm", "fr_oracle_decode_3dmm_nofma"):
+        for name in ("fr_oracle_decode_3dmm", "fr_oracle_decode_3dmm_nofma", "fr_oracle_decode_3dmm_q30"):
             fn = getattr(L, name)
             fn.argtypes = [_f32p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_float, _f32p]
             fn.restype = ctypes.c_int
@@ -155,8 +155,9 @@ def rotation_matrix_batch(angles_batch):
     return np.stack([rotation_matrix(a[i]) for i in range(a.shape[0])]) if a.shape[0] else np.zeros((0, 3, 3), np.float32)
 
 
-def decode_3dmm(params, mu, pc_shape, pc_exp, im_size, R=None, nofma=False):
-    """CPU restatement of FaceRecNet.vertices_transform (nets/network.py:140-171) under the written fp32 spec."""
+def decode_3dmm(params, mu, pc_shape, pc_exp, im_size, R=None, nofma=False, q30=False):
+    """CPU restatement of FaceRecNet.vertices_transform (nets/network.py:140-171) under the written fp32 spec
+    (q30=True: under the written fixed-point spec of the product's int8-MFMA decode, fr_oracle.c "Q30 decode")."""
     params, pp = _c32(params)
     mu, mp = _c32(np.asarray(mu).reshape(-1))
     pc_shape, sp = _c32(pc_shape)
@@ -171,10 +172,16 @@ def decode_3dmm(params, mu, pc_shape, pc_exp, im_size, R=None, nofma=False):
         rp = None
     out = np.empty((B, 3, N), np.float32)
     fn = lib().fr_oracle_decode_3dmm_nofma if nofma else lib().fr_oracle_decode_3dmm
+    if q30:
+        fn = lib().fr_oracle_decode_3dmm_q30
     rc = fn(pp, mp, sp, ep, rp, B, N, ns, ne, float(im_size), out.ctypes.data_as(_f32p))
     if rc != 0:
         raise ValueError("fr_oracle_decode_3dmm rc=%d" % rc)
     return out
+
+
+def decode_3dmm_q30(params, mu, pc_shape, pc_exp, im_size, R=None):
+    return decode_3dmm(params, mu, pc_shape, pc_exp, im_size, R=R, q30=True)
 
 
 def decode_3dmm_f64(params, mu, pc_shape, pc_exp, im_size):
