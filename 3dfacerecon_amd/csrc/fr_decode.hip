@@ -447,12 +447,12 @@ size_t fr_packed_basis_bytes(int N, int n_shape, int n_exp) {
     return packed_q_offset(N, n_shape, n_exp) + (fr_decode_q_supported(n_shape, n_exp) ? fr_packed_q_bytes(N, n_shape, n_exp) : 0);
 }
 
-// Arithmetic of the basis blend: FR_DECODE_ARITH_Q30 (default) or FR_DECODE_ARITH_F32 (the k-ordered fmaf chain).
+// Arithmetic of the basis blend: FR_DECODE_ARITH_F32 (default: the k-ordered fmaf chain) or FR_DECODE_ARITH_Q30.
 static int g_decode_arith = -1;
 int fr_decode_arith_get() {
     if (g_decode_arith < 0) {
         const char* e = getenv("FR_DECODE_ARITH");
-        g_decode_arith = (e && !strcmp(e, "f32")) ? FR_DECODE_ARITH_F32 : FR_DECODE_ARITH_Q30;
+        g_decode_arith = (e && !strcmp(e, "q30")) ? FR_DECODE_ARITH_Q30 : FR_DECODE_ARITH_F32;
     }
     return g_decode_arith;
 }

@@ -13,7 +13,7 @@
 // Entries within 2^-6 of their row's maximum are represented exactly; the quantisation error of the rest is below
 // 2^-31 of the row / column maximum, so the result is the correctly rounded fp32 value of the real-number blend in
 // 99.7 % of the cases on the model's data (mean error 0.25 ulp against the f32 chain's 0.5; tests/test_decode_q30_*.py).
-// The specification is restated in oracle/fr_oracle.c ("Q30 decode") and the kernel is held to it BIT FOR BIT.
+// The specification is restated on the CPU by the test oracle ("Q30 decode") and the kernel is held to it BIT FOR BIT.
 //
 // Packed image (built once by fr_decode_pack_basis, after the f32 image): int ce[S*64] | per 16-vertex tile:
 //   fragment (c, sidx, i): coordinate c, k-step s = (sidx == 0 ? S-1 : sidx-1), digit i; lane l holds 16 bytes:
@@ -22,6 +22,8 @@
 //   their end read the bytes that follow (harmless: the matching parameter digits are zero), and the 256 bytes that
 //   follow the very first fragment of a tile are its payload: per row {mu_x, mu_y, mu_z, -re_x | -re_y << 10 | -re_z << 20}.
 //   With KB % 4 != 0 the payload therefore arrives in lanes 48..63 of the tile's first fragment load, free of charge.
+#include <mutex>
+
 #include "fr_decode_shared.h"
 
 namespace fr {
@@ -174,79 +176,112 @@ struct DecodeQArgs {
     const char* tiles;     // first tile of the Q image
     const int* ce;         // column exponents [S*64]
     QShape qs;
+    const char* stage;     // this pass's staged parameters (q_stage_kernel)
 };
 
 constexpr int Q_BE_BAD = 0x7FFFFFFF;
 
-// Parameters -> LDS as digit fragments (B operand).  Image: [(s*4 + j)*4 + nb][lane] x 16 bytes; lane l of column block
-// nb holds column 16 nb + (l & 15), k = 64 s + 16 (l >> 4) + t.  be_s[b] = the column's exponent (Q_BE_BAD: a
-// non-finite parameter).  Ends with a barrier.
-template <int DEC_BLOCK>
-__device__ __forceinline__ void q_stage_params(const DecodeQArgs& a, char* Bimg, int* be_s, int tid, int nd, int nbatch) {
+// Staging kernel, one launch per pass of <= 64 faces, one workgroup per column b: the face's parameters become digit
+// fragments (B operand), its pose becomes Mt = f.R | t3d (float64 rotation, network.py:266-297), ONCE -- the decode
+// kernel's 256 workgroups then only copy the 64 + 3 KiB image into their LDS (quantising in every workgroup cost 12 us
+// of every CU's time).  Image: [(s*4 + j)*4 + nb][lane] x 16 bytes; lane l of column block nb holds column
+// 16 nb + (l & 15), k = 64 s + 16 (l >> 4) + t; then Mt [64][12] floats, then be [64] ints (the column's exponent;
+// Q_BE_BAD: a non-finite parameter).
+__host__ __device__ inline size_t q_stage_bytes(int S) { return (size_t)S * 16384 + MAXB * 12 * sizeof(float) + MAXB * sizeof(int); }
+__global__ __launch_bounds__(128) void q_stage_kernel(DecodeQArgs a, char* __restrict__ stage) {
+    __shared__ int be_sh;
+    __shared__ double sc_sh[6];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int K = a.qs.K, S = a.qs.S;
-    for (int b = tid; b < MAXB; b += DEC_BLOCK) be_s[b] = INT_MIN;
+    const int nd = FR_N_POSE + a.d.ns + a.d.ne;
+    const int nbatch = min(a.d.B - a.d.b0, MAXB);
+    const bool live = b < nbatch;
+    const float* pr = a.d.params + (size_t)(a.d.b0 + (live ? b : 0)) * nd;
+    if (tid == 0) be_sh = INT_MIN;
     __syncthreads();
-    const int items = MAXB * 4 * S;
-    for (int it = tid; it < items; it += DEC_BLOCK) {
-        const int b = it & 63, u = it >> 6;
-        if (b >= nbatch || 16 * u >= K) continue;
-        const float* prow = a.d.params + (size_t)(a.d.b0 + b) * nd + FR_N_POSE;
-        int e = INT_MIN;
-        bool bad = false;
-#pragma unroll 4
-        for (int t = 0; t < 16; t++) {
-            const int k = 16 * u + t;
-            if (k < K) {
-                const float x = prow[k];
-                if (!isfinite(x)) bad = true;
-                else if (x != 0.f) e = max(e, q_exp_of((double)x) + a.ce[k]);
-            }
-        }
-        if (bad) atomicMax(&be_s[b], Q_BE_BAD);
-        else if (e != INT_MIN) atomicMax(&be_s[b], e);
+    // thread tid owns k = 4 tid .. 4 tid + 3 (one dword of each digit's 16-byte slot)
+    float x[4];
+    int cek[4];
+    const bool mine = 4 * tid < 64 * S;
+    int e = INT_MIN;
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int k = 4 * tid + t;
+        x[t] = (live && k < K) ? pr[FR_N_POSE + k] : 0.f;
+        cek[t] = (mine && k < K) ? a.ce[k] : 0;
+        if (!isfinite(x[t])) bad = true;
+        else if (x[t] != 0.f) e = max(e, __builtin_amdgcn_frexp_expf(x[t]) + cek[t]);
+    }
+    if (bad) atomicMax(&be_sh, Q_BE_BAD);
+    else if (e != INT_MIN) atomicMax(&be_sh, e);
+    if (tid < 3 && live && !a.d.R_override) {
+        double sn, cs;
+        sincos((double)pr[tid], &sn, &cs);
+        sc_sh[2 * tid] = sn;
+        sc_sh[2 * tid + 1] = cs;
     }
     __syncthreads();
-    for (int it = tid; it < items; it += DEC_BLOCK) {
-        const int b = it & 63, u = it >> 6;
-        const int s = u >> 2, g = u & 3;
-        unsigned w[4][4];
+    int be = be_sh;
+    if (be == INT_MIN) be = 0;
+    if (mine) {
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        if (live && be != Q_BE_BAD) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) w[j][q] = 0u;
-        int be = b < nbatch ? be_s[b] : 0;
-        if (be == INT_MIN) be = 0;
-        if (b < nbatch && be != Q_BE_BAD && 16 * u < K) {
-            const float* prow = a.d.params + (size_t)(a.d.b0 + b) * nd + FR_N_POSE;
-#pragma unroll
-            for (int t = 0; t < 16; t++) {
-                const int k = 16 * u + t;
-                if (k < K) {
-                    const int q = (int)rint(ldexp((double)prow[k], a.ce[k] + 30 - be));
-                    int d3 = ((q + 128) & 255) - 128;
-                    int q1 = (q - d3) >> 8;
+            for (int t = 0; t < 4; t++) {
+                if (4 * tid + t < K) {
+                    const int qv = (int)rint(ldexp((double)x[t], cek[t] + 30 - be));
+                    int d3 = ((qv + 128) & 255) - 128;
+                    int q1 = (qv - d3) >> 8;
                     int d2 = ((q1 + 128) & 255) - 128;
                     q1 = (q1 - d2) >> 8;
                     int d1 = ((q1 + 128) & 255) - 128;
                     q1 = (q1 - d1) >> 8;
-                    const int sh = 8 * (t & 3);
-                    w[0][t >> 2] |= (unsigned)(q1 & 255) << sh;
-                    w[1][t >> 2] |= (unsigned)(d1 & 255) << sh;
-                    w[2][t >> 2] |= (unsigned)(d2 & 255) << sh;
-                    w[3][t >> 2] |= (unsigned)(d3 & 255) << sh;
+                    w[0] |= (unsigned)(q1 & 255) << (8 * t);
+                    w[1] |= (unsigned)(d1 & 255) << (8 * t);
+                    w[2] |= (unsigned)(d2 & 255) << (8 * t);
+                    w[3] |= (unsigned)(d3 & 255) << (8 * t);
                 }
             }
         }
-        const int nb = b >> 4;
+        const int u = tid >> 2, s = u >> 2, g = u & 3, nb = b >> 4;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            *reinterpret_cast<uint4*>(Bimg + ((size_t)((s * 4 + j) * 4 + nb) * 64 + g * 16 + (b & 15)) * 16) =
-                make_uint4(w[j][0], w[j][1], w[j][2], w[j][3]);
+            *reinterpret_cast<unsigned*>(stage + ((size_t)((s * 4 + j) * 4 + nb) * 64 + g * 16 + (b & 15)) * 16 + 4 * (tid & 3)) = w[j];
     }
+    if (tid == 0) {
+        float* Mt = reinterpret_cast<float*>(stage + (size_t)S * 16384) + b * 12;
+        int* be_o = reinterpret_cast<int*>(stage + (size_t)S * 16384 + MAXB * 12 * sizeof(float));
+        float m[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) m[i] = 0.f;
+        if (live) {
+            float R[9];
+            if (a.d.R_override) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) R[i] = a.d.R_override[(size_t)(a.d.b0 + b) * 9 + i];
+            } else {
+                rotation_from_sincos(sc_sh[0], sc_sh[1], sc_sh[2], sc_sh[3], sc_sh[4], sc_sh[5], R);
+            }
+            const float f = pr[6];
+#pragma unroll
+            for (int i = 0; i < 9; i++) m[i] = f * R[i];  // f (.) R elementwise, network.py:163-165
+            m[9] = pr[3];
+            m[10] = pr[4];
+            m[11] = pr[5];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) Mt[i] = m[i];
+        be_o[b] = live ? be : 0;
+    }
+}
+// staged image -> LDS (the decode kernels' whole prologue); ends with a barrier
+template <int DEC_BLOCK>
+__device__ __forceinline__ void q_copy_stage(const char* __restrict__ stage, char* lds, int S, int tid) {
+    const int n16 = (int)(q_stage_bytes(S) / 16);
+    for (int i = tid; i < n16; i += DEC_BLOCK)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(stage)[i];
     __syncthreads();
-    for (int b = tid; b < MAXB; b += DEC_BLOCK)
-        if (be_s[b] == INT_MIN) be_s[b] = 0;
-    // (the caller's pose_prologue barriers publish be_s)
 }
 
 // One coordinate's seven level sums -> fl32(mu + I 2^(re + be - 60)) for this lane's 4 rows x NBW columns.
@@ -277,13 +312,11 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_q_kernel(DecodeQArgs a)
     const QShape qs = a.qs;
     char* Bimg = qsmem;                                                   // S * 16 KiB
     float* Mt = reinterpret_cast<float*>(Bimg + (size_t)qs.S * 16384);     // [64][12]
-    double* SC = reinterpret_cast<double*>(Mt + MAXB * 12);                // [64][3][2]
-    int* be_s = reinterpret_cast<int*>(SC + MAXB * 6);                     // [64]
+    int* be_s = reinterpret_cast<int*>(Mt + MAXB * 12);                    // [64]
     const int tid = threadIdx.x;
     const int nd = FR_N_POSE + a.d.ns + a.d.ne;
     const int nbatch = min(a.d.B - a.d.b0, MAXB);
-    q_stage_params<DEC_BLOCK>(a, Bimg, be_s, tid, nd, nbatch);
-    pose_prologue<MAXB>(a.d, Mt, SC, tid, nd, nbatch);
+    q_copy_stage<DEC_BLOCK>(a.stage, qsmem, qs.S, tid);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int tiles = tiles_of(a.d.N);
@@ -336,6 +369,151 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_q_kernel(DecodeQArgs a)
     }
 }
 
+// ---- streaming variant for the model's basis shape (199 + 29 coefficients: KB = 15, S = 4, last k-step 3 groups) -------
+// Same arithmetic, different schedule (the one fr_decode.hip's ring kernel uses): a wave owns whole tiles (all NBW column
+// blocks, so every basis byte is requested by exactly one wave of the chip) and treats its tiles as ONE stream of 1 KiB
+// fragment requests through a ring of R registers quadruples, consumed four at a time (the four digits of a k-step, each
+// used against the four parameter digits: 16 MFMAs x NBW per ring group).  The requests are inline asm so that the
+// compiler can neither reorder nor drain them; the only waits are counted s_waitcnt vmcnt(R-4).  The tile's payload
+// rides in lanes 48..63 of its first (768-byte) fragment and is parked in LDS; finished x / y rows wait in LDS for z.
+#define FRQ_LD(dst, sbase, voff)                                                                                  \
+    {                                                                                                             \
+        if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase)); \
+        else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));                 \
+    }
+template <int R>
+__device__ __forceinline__ void q_ring_wait4(i32x4& a0, i32x4& a1, i32x4& a2, i32x4& a3) {
+    static_assert(R == 8 || R == 12 || R == 16, "ring size");
+    if constexpr (R == 8) asm volatile("s_waitcnt vmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    else if constexpr (R == 12) asm volatile("s_waitcnt vmcnt(8)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    else asm volatile("s_waitcnt vmcnt(12)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+}
+constexpr int QR_KB = 15, QR_S = 4, QR_NGL = 3, QR_F = 48;
+constexpr size_t QR_CB = (size_t)1024 * QR_KB, QR_TB = 3 * QR_CB + 256;
+__host__ __device__ constexpr size_t qr_off(int f) {
+    return (size_t)(f / 16) * QR_CB +
+           (((f % 16) / 4) == 0 ? (size_t)(f % 4) * 256 * QR_NGL
+                                : (size_t)4 * 256 * QR_NGL + (size_t)(((f % 16) / 4) - 1) * 4096 + (size_t)(f % 4) * 1024) +
+           (f ? 256 : 0);
+}
+
+template <int R, int NBW, int DEC_WAVES, int WPE, bool NT>
+__global__ __launch_bounds__(DEC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void decode_q_ring_kernel(DecodeQArgs a) {
+    constexpr int DEC_BLOCK = DEC_WAVES * 64;
+    constexpr int F = QR_F;
+    static_assert(F % R == 0 && R % 4 == 0, "the ring must close on an item boundary, in whole groups");
+    extern __shared__ __attribute__((aligned(16))) char qsmem[];
+    char* Bimg = qsmem;                                                        // 4 k-steps x 16 KiB
+    float* Mt = reinterpret_cast<float*>(Bimg + (size_t)QR_S * 16384);          // [64][12]
+    int* be_s = reinterpret_cast<int*>(Mt + MAXB * 12);                         // [64]
+    uint4* pay_s = reinterpret_cast<uint4*>(be_s + MAXB);                       // [DEC_WAVES][16]
+    f32x4* park_s = reinterpret_cast<f32x4*>(pay_s + DEC_WAVES * 16);           // [DEC_WAVES][2][NBW][64]
+    const int tid = threadIdx.x;
+    const int nd = FR_N_POSE + a.d.ns + a.d.ne;
+    const int nbatch = min(a.d.B - a.d.b0, MAXB);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = tiles_of(a.d.N);
+    const int N = a.d.N;
+    const TileWalk tw = tile_walk(wave, DEC_WAVES, (int)blockIdx.x, (int)gridDim.x);
+    const int tile0 = tw.first, tstride = tw.stride;
+    const unsigned voffA = (unsigned)lane * 16u;
+    const char* Tb = a.tiles;
+
+    i32x4 ring[R];
+#define FRQ_REQ(slot_, f_, t_)                                                   \
+    {                                                                            \
+        const char* sb_ = Tb + (size_t)(t_) * QR_TB + qr_off(f_);                \
+        FRQ_LD(ring[slot_], sb_, voffA);                                         \
+    }
+    {
+        const int t0c = tile0 < tiles ? tile0 : 0;
+#pragma unroll
+        for (int f = 0; f < R; f++) FRQ_REQ(f, f, t0c)
+    }
+    q_copy_stage<DEC_BLOCK>(a.stage, qsmem, QR_S, tid);
+    if (tile0 >= tiles) {
+#pragma unroll
+        for (int f = 0; f < R; f++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[f]));
+        return;
+    }
+    int be[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; nb++) be[nb] = be_s[16 * nb + (lane & 15)];
+    uint4* pay_w = pay_s + wave * 16;
+    f32x4* park_w = park_s + (size_t)wave * 2 * NBW * 64 + lane;
+    const char* Bl = Bimg + (size_t)lane * 16;
+
+    for (int ct = tile0; ct < tiles; ct += tstride) {
+        int nt = ct + tstride;
+        if (nt >= tiles) nt = tile0;   // past the end: harmless re-request of a valid address, never consumed
+        i32x4 acc[7][NBW];
+#pragma unroll
+        for (int g = 0; g < F / 4; g++) {
+            const int f0 = 4 * g, c = g / 4, sidx = g % 4;
+            const int s = sidx == 0 ? QR_S - 1 : sidx - 1;
+            if (sidx == 0) {
+#pragma unroll
+                for (int l = 0; l < 7; l++)
+#pragma unroll
+                    for (int nb = 0; nb < NBW; nb++) acc[l][nb] = (i32x4){0, 0, 0, 0};
+            }
+            q_ring_wait4<R>(ring[f0 % R], ring[(f0 + 1) % R], ring[(f0 + 2) % R], ring[(f0 + 3) % R]);
+            if (g == 0) {
+                if (lane >= 48) {
+                    const i32x4 p = ring[0];
+                    pay_w[lane - 48] = make_uint4((unsigned)p[0], (unsigned)p[1], (unsigned)p[2], (unsigned)p[3]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                i32x4 bf[NBW];
+#pragma unroll
+                for (int nb = 0; nb < NBW; nb++)
+                    bf[nb] = *reinterpret_cast<const i32x4*>(Bl + (size_t)((s * 4 + j) * 4 + nb) * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int nb = 0; nb < NBW; nb++)
+                        acc[i + j][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[(f0 + i) % R], bf[nb], acc[i + j][nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (f0 + i + R < F) FRQ_REQ((f0 + i) % R, f0 + i + R, ct)
+                else FRQ_REQ((f0 + i) % R, f0 + i + R - F, nt)
+            }
+            if (sidx == 3) {   // coordinate c complete
+                float mu4[4];
+                int e4[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint4 row = pay_w[4 * (lane >> 4) + r];
+                    mu4[r] = __uint_as_float(c == 0 ? row.x : c == 1 ? row.y : row.z);
+                    e4[r] = (int)((row.w >> (10 * c)) & 1023u);
+                }
+                f32x4 vz[NBW];
+                q_finish<NBW>(acc, mu4, e4, be, vz);
+                if (c < 2) {
+#pragma unroll
+                    for (int nb = 0; nb < NBW; nb++) park_w[(size_t)(c * NBW + nb) * 64] = vz[nb];
+                } else {
+                    f32x4 vx[NBW], vy[NBW];
+#pragma unroll
+                    for (int nb = 0; nb < NBW; nb++) {
+                        vx[nb] = park_w[(size_t)nb * 64];
+                        vy[nb] = park_w[(size_t)(NBW + nb) * 64];
+                    }
+                    decode_store<NBW>(a.d, vx, vy, vz, Mt, ct, 0, lane, nbatch, N);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < R; f++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[f]));
+#undef FRQ_REQ
+}
+
 }  // namespace fr
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -358,6 +536,32 @@ static unsigned* q_colmax_scratch(int K) {  // per-device scratch for the column
         cap[dev] = K + 64;
     }
     return buf[dev];
+}
+
+// Per-(device, stream) staging buffer of the decode (68 KiB for the model's shape), allocated on first use and kept:
+// launches on one stream are ordered, so its passes can share one buffer; different streams must not.
+static char* q_stage_scratch(hipStream_t stream, size_t bytes) {
+    struct Ent { int dev; hipStream_t stream; char* p; size_t cap; };
+    static Ent tab[64];
+    static int used = 0;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < used; i++)
+        if (tab[i].dev == dev && tab[i].stream == stream) {
+            if (tab[i].cap >= bytes) return tab[i].p;
+            char* np = nullptr;   // (a larger basis shape on the same stream: the old buffer may still be in use -- keep it)
+            if (hipMalloc(&np, bytes) != hipSuccess) return nullptr;
+            tab[i].p = np;
+            tab[i].cap = bytes;
+            return np;
+        }
+    if (used == 64) return nullptr;
+    char* np = nullptr;
+    if (hipMalloc(&np, bytes) != hipSuccess) return nullptr;
+    tab[used++] = Ent{dev, stream, np, bytes};
+    return np;
 }
 
 int fr_launch_pack_q(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
@@ -396,6 +600,18 @@ static int launch_q_generic(const fr::DecodeQArgs& a, size_t lds, int cus, hipSt
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
+template <int R, int NBW, int WAVES, bool NT>
+static int launch_q_ring(const fr::DecodeQArgs& a, int cus, hipStream_t stream) {
+    static unsigned char lds_ok[64];
+    const void* k = reinterpret_cast<const void*>(&fr::decode_q_ring_kernel<R, NBW, WAVES, WAVES / 4, NT>);
+    if (fr_allow_full_lds(k, lds_ok) != hipSuccess) return FR_ERR_LAUNCH;
+    const size_t lds = fr::q_stage_bytes(fr::QR_S) + (size_t)WAVES * 256 + (size_t)WAVES * 2 * NBW * 1024;
+    const int tiles = fr::tiles_of(a.d.N);
+    const int grid = (int)min((long long)cus, (long long)(tiles + WAVES - 1) / WAVES);
+    hipLaunchKernelGGL((fr::decode_q_ring_kernel<R, NBW, WAVES, WAVES / 4, NT>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
+}
+
 int fr_launch_decode_q(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
                        int n_exp, float im_size, float* vertex_proj, int cus, hipStream_t stream) {
     using namespace fr;
@@ -412,11 +628,23 @@ int fr_launch_decode_q(const float* params, const void* qimage, const float* R_o
     a.d.B = B; a.d.N = N; a.d.ns = n_shape; a.d.ne = n_exp;
     a.d.halves = 1;
     a.d.im_size = im_size;
-    const size_t lds = (size_t)a.qs.S * 16384 + MAXB * 12 * sizeof(float) + MAXB * 6 * sizeof(double) + MAXB * sizeof(int);
+    const size_t lds = q_stage_bytes(a.qs.S);
     if (lds > 160 * 1024) return FR_ERR_UNSUPPORTED;
+    char* stage = q_stage_scratch(stream, lds);
+    if (!stage) return FR_ERR_LAUNCH;
+    a.stage = stage;
     for (int b0 = 0; b0 < B; b0 += MAXB) {
         a.d.b0 = b0;
+        hipLaunchKernelGGL(q_stage_kernel, dim3(MAXB), dim3(128), 0, stream, a, stage);
         const int nbt = (min(B - b0, MAXB) + 15) / 16;
+        static const bool loop_env = getenv("FR_DECODE_IMPL") && !strcmp(getenv("FR_DECODE_IMPL"), "loop");
+        if (!loop_env && a.qs.KB == QR_KB) {   // the model's basis shape: streaming schedule
+            int rc = nbt == 1 ? launch_q_ring<16, 1, 8, true>(a, cus, stream)
+                     : nbt == 2 ? launch_q_ring<16, 2, 8, true>(a, cus, stream)
+                                : launch_q_ring<16, 4, 8, true>(a, cus, stream);
+            if (rc != FR_OK) return rc;
+            continue;
+        }
         int rc = nbt == 1 ? launch_q_generic<1>(a, lds, cus, stream)
                  : nbt == 2 ? launch_q_generic<2>(a, lds, cus, stream)
                             : launch_q_generic<4>(a, lds, cus, stream);

@@ -122,15 +122,15 @@ int fr_decode_pack_basis(const float* mu, const float* pc_shape, const float* pc
  *   vertex_proj [B,3,N]; y row is (im_size - y) - 1 (network.py:167-169).
  * Numerical definition: the reference evaluates S = pc_shape.alpha and E = pc_exp.beta with two fp32
  * tf.matmuls whose summation order is unspecified (network.py:153-156).  Two written definitions are offered:
- *   FR_DECODE_ARITH_Q30 (default)  v = fl32(mu + S + E) with S + E an EXACT fixed-point dot product of the operands
+ *   FR_DECODE_ARITH_F32 (default)  S, E = k-ordered fmaf chains from +0, v = (mu + S) + E  (the f32-input MFMA; the
+ *       reference's own arithmetic type).
+ *   FR_DECODE_ARITH_Q30            v = fl32(mu + S + E) with S + E an EXACT fixed-point dot product of the operands
  *       quantised to 31 bits against power-of-two row / column scales (int8 matrix cores, 16 digit products): the
- *       correctly rounded fp32 value of the real-number blend in > 99 % of the cases, never worse than 2^-30 of the
- *       row's largest term per coefficient; a non-finite parameter makes the face's vertices NaN.  n_shape + n_exp
- *       above 512 falls back to F32.
- *   FR_DECODE_ARITH_F32            S, E = k-ordered fmaf chains from +0, v = (mu + S) + E  (the f32-input MFMA;
- *       round 1's definition, ~2x the rounding error of Q30 and 1.6x its time).
+ *       correctly rounded fp32 value of the real-number blend in > 99 % of the cases (half the f32 chain's mean error);
+ *       a non-finite parameter makes the face's vertices NaN.  n_shape + n_exp above 512 falls back to F32.  Measured
+ *       6 % slower than F32 inside the 64-face pipeline, hence not the default.
  * Both are restated on the CPU in oracle/fr_oracle.c and the kernels are held to them bit for bit.  The choice is a
- * process-wide setting (initial value from the environment variable FR_DECODE_ARITH = "q30" | "f32"). */
+ * process-wide setting (initial value from the environment variable FR_DECODE_ARITH = "f32" | "q30"). */
 #define FR_DECODE_ARITH_Q30 0
 #define FR_DECODE_ARITH_F32 1
 int fr_decode_set_arith(int mode);   /* FR_OK or FR_ERR_INVALID_ARG */

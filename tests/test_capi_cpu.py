@@ -92,11 +92,17 @@ def test_render_geometry_window_never_spans_three_strips():
 
 def test_packed_basis_size():
     L = pkg("_lib").lib()
-    # tiles of 16 vertices; 16-wide k groups for shape and exp separately; + packed mu
+    # two images.  f32: tiles of 16 vertices; 16-wide k groups for shape and exp separately; + packed mu.
+    # Q30 (256-byte aligned after it): 64 ints of column exponents per k-step of 64, then per tile 3 coordinates x
+    # ceil(228 / 16) = 15 live 16-k groups x 4 digits x 256 bytes + a 256-byte payload (mu, row exponents); + 1 KiB slack
     n = L.fr_decode_packed_basis_bytes(53215, 199, 29)
     tiles, G = (53215 + 15) // 16, 13 + 2
-    assert n == tiles * G * 3 * 64 * 16 + tiles * 3 * 16 * 4
-    assert L.fr_decode_packed_basis_bytes(0, 199, 29) == 0
+    f32 = tiles * G * 3 * 64 * 16 + tiles * 3 * 16 * 4
+    q30 = 4 * 64 * 4 + tiles * (3 * 15 * 4 * 256 + 256) + 1024
+    assert n == (f32 + 255) // 256 * 256 + q30
+    # more than 512 coefficients: the Q30 kernels do not take the shape, only the f32 image is kept
+    t2 = (100 + 15) // 16
+    assert L.fr_decode_packed_basis_bytes(100, 600, 10) == (t2 * (38 + 1) * 3 * 64 * 16 + t2 * 3 * 16 * 4 + 255) // 256 * 256
 
 
 def test_ops_module_surface_mirrors_reference():
