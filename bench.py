@@ -234,10 +234,16 @@ def main():
         # owns the vertex / triangle / texture reads, the resolve kernel the four output planes
         emit_bytes = (4.0 * 3 * N + (4.0 * 3 * T + 4.0 * 3 * N) / B) * B
         resolve_bytes = 4.0 * H * W * 8 * B
-        roof_decode = {"bound": "mfma", "kernel": "decode_ring_kernel<13,2,8,2,16,64> (fr_decode_3dmm)",
-                       "achieved": flops / (decode_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "traffic": None, "avg_ms": decode_ms, "algorithmic_flop_per_launch": flops,
-                       "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9}
+        q30 = pkg("_lib").lib().fr_decode_get_arith() == 0   # FR_DECODE_ARITH=q30 (opt-in; the default is the f32 chain)
+        if q30:   # int8-MFMA blend: the matrix pipe is no longer the bound, the 153 MB basis + 41 MB output stream is
+            roof_decode = {"bound": "hbm", "kernel": "q_stage_kernel + decode_q_ring_kernel<16,4,8> (fr_decode_3dmm, Q30)",
+                           "achieved": ab["decode"] * B / (decode_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "traffic": None, "avg_ms": decode_ms, "algorithmic_bytes_per_launch": ab["decode"] * B}
+        else:
+            roof_decode = {"bound": "mfma", "kernel": "decode_ring_kernel<13,2,8,2,16,64> (fr_decode_3dmm)",
+                           "achieved": flops / (decode_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "traffic": None, "avg_ms": decode_ms, "algorithmic_flop_per_launch": flops,
+                           "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9}
         roof_emit = {"bound": "hbm", "kernel": "raster_emit_kernel (fr_render_depth_forward, phase 1)",
                      "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "traffic": None, "avg_ms": emit_ms, "algorithmic_bytes_per_launch": emit_bytes}
@@ -249,11 +255,13 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pmc.get("batch") == B and (H, W) == (200, 200):
-                roof_decode["traffic"] = pmc["decode_bytes_per_launch"]
+                if not q30:
+                    roof_decode["traffic"] = pmc["decode_bytes_per_launch"]
                 roof_emit["traffic"] = pmc["render_split"]["raster_emit_kernel"]
                 roof_resolve["traffic"] = pmc["render_split"]["resolve_write_kernel"]
                 for r in (roof_decode, roof_emit, roof_resolve):
-                    r["traffic_source"] = "profiles/pmc_traffic.json"
+                    if r["traffic"] is not None:
+                        r["traffic_source"] = "profiles/pmc_traffic.json"
         except (OSError, ValueError, KeyError):
             pass
         kernels = {"decode": roof_decode, "raster_emit": roof_emit, "resolve_write": roof_resolve}
@@ -278,6 +286,7 @@ def main():
                        "faces_per_gpu": B, "nver": N, "ntri": T, "n_shape": net.ndim_shape, "n_exp": net.ndim_exp,
                        "sampler": "sample_test.py:23-38 beta=0.7 seed=3456+rank", "coverage": cov,
                        "sharding": "batch over ranks, no data-path collective",
+                       "decode_arith": "q30 (exact fixed point on the int8 MFMA)" if q30 else "f32 fmaf chain (f32-input MFMA)",
                        "constants": "the packed basis (fr_decode_pack_basis) and the pre-validated triangle table "
                                     "(fr_render_depth_forward_phases, phase 4) are built once per plan: both are "
                                     "tf.constants of the reference model (network.py:41-43, 178); a caller that repacks the "

@@ -34,7 +34,7 @@ def kernel_stats(name, out):
                                  for r in hot}}
 
 
-for j in ("bench", "bench_k20", "bench_graph"):
+for j in ("bench", "bench_k20", "bench_graph", "bench_q30"):
     f = os.path.join(src, j + ".json")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.json" % (tag, j)))

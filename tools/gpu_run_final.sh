@@ -9,6 +9,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 --cpu-faces 0 > $O/bench_k20.json 2>> $O/bench.err
 python bench.py --graph --cpu-faces 0 > $O/bench_graph.json 2>> $O/bench.err
+FR_DECODE_ARITH=q30 python bench.py --cpu-faces 0 > $O/bench_q30.json 2>> $O/bench.err
 BCMD="python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- $BCMD > $O/prof_bench.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -- $BCMD > $O/pmc_fetch.log 2>&1
@@ -29,6 +30,6 @@ find $O -name "*counter_collection.csv" -size +1M -delete
 find $O -name "*.db" -delete
 tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; python -c "
 import json
-for f in ('bench','bench_k20','bench_graph'):
+for f in ('bench','bench_k20','bench_graph','bench_q30'):
     d=json.load(open('$O/%s.json'%f)); print(f, round(d['value']), d['ms_per_step'], d.get('value_min'), d.get('value_max'), {k:round(v['avg_ms']*1e3,1) for k,v in d['kernels'].items()}, d.get('graph_replay_faces_per_s'))
 "; cat $O/kernel_timing.log; cat $O/config3_fwd.json $O/config4_train_shard.json $O/config5_fine448_shard.json
