@@ -10,6 +10,43 @@ from conftest import pkg as pkg_mod
 pytestmark = pytest.mark.gpu
 
 
+def test_params_to_depth_q30(oracle, full_assets, synth):
+    """The same chain with the opt-in Q30 decode arithmetic: bit-exact against its own CPU spec -> oracle rasteriser, and
+    its depth against the float64 decode recorded next to the f32 chain's (a correctly rounded blend leaves only the
+    fp32 pose product's roundings)."""
+    A = full_assets
+    L = pkg_mod("_lib").lib()
+    prev = L.fr_decode_get_arith()
+    L.fr_decode_set_arith(0)
+    try:
+        P = synth.sample_params_batch(2, beta=0.7, seed=3456)
+        R = oracle.rotation_matrix_batch(P[:, :3])
+        net = net_mod().FaceRecNet(mesh_data=A, batch_size=2, im_size=200)
+        V = net.vertices_transform(torch.as_tensor(P, device="cuda:0")[:, None, None, :], R=torch.as_tensor(R, device="cuda:0"))
+        outs = ops().render_depth(V, net.tri, net.vertex_code, torch.zeros((2, 200, 200, 3), device="cuda:0"))
+        got = tuple(o.cpu().numpy() for o in outs)
+    finally:
+        L.fr_decode_set_arith(prev)
+    Vo = oracle.decode_3dmm_q30(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R)
+    assert_render_equal(got, oracle.render_depth(Vo, A["tri"], A["vertex"][None], 200, 200), "params->depth (q30)")
+    V64 = oracle.decode_3dmm_f64(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0)
+    want64 = oracle.render_depth(V64.astype(np.float32), A["tri"], A["vertex"][None], 200, 200)
+    same = (want64[3] == got[3]) & (got[3] >= 0)
+    d = np.abs(got[0][same].astype(np.float64) - want64[0][same].astype(np.float64))
+    report = {"decode_arith": "q30", "pixels_compared": int(same.sum()), "max_abs_ddepth": float(d.max()),
+              "frac_within_1e-5": float((d <= 1e-5).mean()), "frac_bit_equal": float((d == 0).mean()),
+              "tri_ind_disagree_frac": float((want64[3] != got[3]).mean())}
+    print("params->depth vs float64 decode (q30):", report)
+    try:
+        import json, os
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(report, open("gpurun_out/parity_depth_vs_f64_q30.json", "w"), indent=1)
+    except OSError:
+        pass
+    assert report["frac_within_1e-5"] >= 0.97 and report["tri_ind_disagree_frac"] < 2e-3
+    assert report["max_abs_ddepth"] <= 4.0 * float(np.spacing(np.float32(np.abs(want64[0][same]).max()))) + 1e-12
+
+
 def test_params_to_depth_bit_exact(oracle, full_assets, synth):
     A = full_assets
     P = synth.sample_params_batch(2, beta=0.7, seed=3456)
