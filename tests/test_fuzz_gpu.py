@@ -131,3 +131,63 @@ def test_decode_both_arithmetics(oracle, synth, seed):
             np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg="seed %d %s" % (seed, "q30" if q30 else "f32"))
     finally:
         L.fr_decode_set_arith(prev)
+
+
+@pytest.mark.parametrize("seed", range(max(1, N_RENDER // 4)))
+def test_fused_rendering_layer(oracle, seed):
+    """fr_rendering_layer_forward (render + network.py:185-199 in one pass) on the finite scene kinds: depth / tri_ind and
+    the post-processed channels bit-exact against the oracle's planes pushed through the same fp32 formulas in numpy."""
+    s = 5000 + seed
+    while True:
+        ver, tri, tex, H, W = _scene(s)
+        if np.isfinite(ver).all() and np.isfinite(tri).all():
+            break
+        s += 100000
+    B = ver.shape[0]
+    im = np.random.RandomState(seed).uniform(0, 1, (B, H, W, 1)).astype(np.float32)
+    t = lambda a: torch.as_tensor(a, device="cuda:0")  # noqa: E731
+    net_in, depth_img, depth, tri_ind = ops().rendering_layer_fused(t(ver), t(tri), t(tex), t(im))
+    d, tx, n, ti = oracle.render_depth(ver, tri, tex, H, W)
+    np.testing.assert_array_equal(depth.cpu().numpy(), d)
+    np.testing.assert_array_equal(tri_ind.cpu().numpy(), ti)
+    np.testing.assert_array_equal(net_in[..., 1:4].cpu().numpy(), np.clip(tx, np.float32(1e-6), np.float32(1.0)))
+    np.testing.assert_array_equal(net_in[..., 0:1].cpu().numpy(), np.clip(d, np.float32(1e-6), np.float32(1.0)) * im)
+    np.testing.assert_array_equal(depth_img.cpu().numpy(), np.maximum(d, np.float32(1e-6)))
+    nn = n.copy()
+    nn[nn[..., 2] < 0] *= -1.0
+    with np.errstate(over="ignore", invalid="ignore"):
+        mag = (nn[..., 0] * nn[..., 0] + nn[..., 1] * nn[..., 1]) + nn[..., 2] * nn[..., 2]
+        mag = np.where(mag > np.float32(1e-6), mag, np.float32(1.0)).astype(np.float32)
+        want = (nn / (np.sqrt(mag) + np.float32(1e-6))[..., None]).astype(np.float32)
+    np.testing.assert_array_equal(net_in[..., 4:7].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("seed", range(max(1, N_RENDER // 8)))
+def test_decode_backward(oracle, synth, seed):
+    """fr_decode_3dmm_backward vs the float64 gradient, random basis shapes and batches; bit-reproducible."""
+    rs = np.random.RandomState(7000 + seed)
+    gu, gv = int(rs.randint(2, 24)), int(rs.randint(2, 24))
+    ns = int(rs.choice([1, 5, 16, 17, 64, 100, 199]))
+    ne = int(rs.choice([1, 3, 16, 29]))
+    B = int(rs.choice([1, 2, 16, 17, 33, 64, 65]))
+    A = synth.make_assets(gu, gv, ns, ne, patch=None, seed_basis=seed)
+    P = np.zeros((B, 7 + ns + ne), np.float32)
+    P[:, 0:3] = rs.uniform(-1.0, 1.0, (B, 3))
+    P[:, 3:5] = rs.uniform(60, 140, (B, 2))
+    P[:, 5] = rs.uniform(-1, 1, B)
+    P[:, 6] = rs.uniform(2e-4, 1e-3, B)
+    P[:, 7:7 + ns] = rs.uniform(0, 1e4, (B, ns))
+    P[:, 7 + ns:] = rs.uniform(-1.5, 1.5, (B, ne))
+    G = rs.standard_normal((B, 3, gu * gv)).astype(np.float32)
+    net = net_mod().FaceRecNet(mesh_data=A, batch_size=B, im_size=200)
+    grads = []
+    for _ in range(2):
+        p = torch.as_tensor(P, device="cuda:0").requires_grad_(True)
+        net.vertices_transform(p).backward(torch.as_tensor(G, device="cuda:0"))
+        grads.append(p.grad.cpu().numpy().astype(np.float64))
+    np.testing.assert_array_equal(grads[0], grads[1])
+    want = oracle.decode_3dmm_backward_f64(G, P, A["mu"], A["pc_shape"], A["pc_exp"])
+    assert np.all(grads[0][:, 0:3] == 0)
+    for sl in (slice(3, 6), slice(6, 7), slice(7, 7 + ns), slice(7 + ns, None)):
+        scale = np.abs(want[:, sl]).max() + 1e-30
+        assert np.abs(grads[0][:, sl] - want[:, sl]).max() / scale < 2e-5, (seed, sl)
