@@ -177,20 +177,23 @@ def test_shard_range_partitions():
         d.shard_range(4, 2, 2)
 
 
-def test_ring_decode_kernel_keeps_its_stream_in_registers():
-    """decode_ring_kernel issues its A-fragment requests through inline asm and counts them by hand (s_waitcnt vmcnt(R-1)):
-    that accounting is only valid if the compiler neither spills an in-flight ring slot nor adds scratch traffic, which
-    shares the vmcnt counter.  The compiler's own resource report must show no scratch for every instantiation."""
+@pytest.mark.parametrize("source,prefix,min_kernels", [("fr_decode.hip", "_ZN2fr18decode_ring_kernel", 2),
+                                                        ("fr_decode_q.hip", "_ZN2fr20decode_q_ring_kernel", 3)])
+def test_ring_decode_kernel_keeps_its_stream_in_registers(source, prefix, min_kernels):
+    """The ring kernels (f32 chain and Q30) issue their A-fragment requests through inline asm and count them by hand
+    (s_waitcnt vmcnt(R-1) / vmcnt(R-4)): that accounting is only valid if the compiler neither spills an in-flight ring
+    slot nor adds scratch traffic, which shares the vmcnt counter.  The compiler's own resource report must show no
+    scratch for every instantiation."""
     import subprocess
     h = pkg("_lib")
-    src = os.path.join(h._CSRC, "fr_decode.hip")
+    src = os.path.join(h._CSRC, source)
     cmd = [h._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", "--cuda-device-only",
            "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, src]
     out = subprocess.run(cmd, cwd=h._CSRC, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     blocks = re.split(r"remark: Function Name: ", out.stderr)[1:]
-    ring = [b for b in blocks if b.startswith("_ZN2fr18decode_ring_kernel")]
-    assert len(ring) >= 2
+    ring = [b for b in blocks if b.startswith(prefix)]
+    assert len(ring) >= min_kernels
     for b in ring:
         assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", b), b[:400]
         assert re.search(r"VGPRs Spill: 0\b", b), b[:400]
@@ -200,9 +203,9 @@ def test_ring_decode_kernel_keeps_its_stream_in_registers():
     asm_out = subprocess.run(cmd[:-4] + ["-S", "-o", "-", src], cwd=h._CSRC, capture_output=True, text=True)
     assert asm_out.returncode == 0, asm_out.stderr[-2000:]
     lines = asm_out.stdout.split("\n")
-    starts = [i for i, l in enumerate(lines) if l.startswith("_ZN2fr18decode_ring_kernel")]
+    starts = [i for i, l in enumerate(lines) if l.startswith(prefix)]
     ends = [i for i, l in enumerate(lines) if l.startswith(".Lfunc_end")]
-    assert len(starts) >= 2
+    assert len(starts) >= min_kernels
     for si in starts:
         body = lines[si:min(e for e in ends if e > si)]
         loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l and ", s[" in l]
