@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 # SURVEY.md 8(d) algorithmic bytes / flops (N=53,215, T=105,840, K=228, H=W=200)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # same guide: the measured copy rate (SURVEY.md 8d asks for the fraction of both)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: exact-f32 MFMA == fp32 vector peak
 
 
@@ -295,7 +296,8 @@ def main():
             "kernels": kernels,
             "pipeline_hbm": {"bytes_per_face": ab["pipeline"],
                              "achieved_GBs": ab["pipeline"] * value / world / 1e9,
-                             "frac_of_8TBs": ab["pipeline"] * value / world / 1e9 / HBM_PEAK_GBS},
+                             "frac_of_8TBs": ab["pipeline"] * value / world / 1e9 / HBM_PEAK_GBS,
+                             "frac_of_measured_copy_6.29TBs": ab["pipeline"] * value / world / 1e9 / HBM_COPY_GBS},
         }
         if graph_fps is not None:
             out["graph_replay_faces_per_s"] = graph_fps
