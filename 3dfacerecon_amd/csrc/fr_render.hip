@@ -519,6 +519,23 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             surv[u] = valid[u] && (fx0 >= 0.0f) && (fy0 >= 0.0f) && (fx1 <= a.wm1) && (fy1 <= a.hm1) && !(fx1 < fx0) &&
                       !(fy1 < fy0);
             single[u] = (fx0 == fx1) && (fy0 == fy1);
+            // A bbox with a single pixel centre (78 % of the survivors on a sub-pixel mesh) misses that centre about half
+            // of the time.  The certified fp32 inside test of phase B (same expressions, same pixel, see there) is cheap
+            // enough to run here, on the sparse lanes: a triangle it certifies as a MISS can emit nothing and is dropped
+            // before the compaction, so that phase B runs on ~40 % fewer lanes; anything it cannot certify stays.  (Flagging
+            // the certified HITS so that phase B skips their test measured no further gain.)
+            if ((a.use_filter & 2) && surv[u] && single[u]) {
+                const float v0x = x3[u] - x1[u], v0y = y3[u] - y1[u], v1x = x2[u] - x1[u], v1y = y2[u] - y1[u];
+                const float D = v0x * v1y - v0y * v1x;
+                const float M0 = fmaxf(fmaxf(fabsf(v0x), fabsf(v0y)), fmaxf(fabsf(v1x), fabsf(v1y)));
+                const float S = M0 * M0;
+                const float v2x = fx0 - x1[u], v2y = fy0 - y1[u];
+                const float A = v2x * v1y - v2y * v1x, Bq = v0x * v2y - v0y * v2x, C = (D - A) - Bq;
+                const bool certain = (M0 < 1073741824.0f) && (M0 > 9.094947017729282e-13f) && (fabsf(D) >= 0.00390625f * S) &&
+                                     fminf(fminf(fabsf(A), fabsf(Bq)), fabsf(C)) >= 1.52587890625e-05f * S;
+                const bool in = D > 0.0f ? fminf(fminf(A, Bq), C) > 0.0f : fmaxf(fmaxf(A, Bq), C) < 0.0f;
+                if (certain && !in) surv[u] = false;
+            }
             // per-triangle texture mean ((t1+t2)+t3)/3 in fp32 (render_depth_op.cc:223) when the texture is shared by the
             // batch: computed once, by face 0's workgroups, for every valid triangle
             if (a.tex_stride == 0 && b == 0 && valid[u]) {
@@ -607,7 +624,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
                 const float S = M0 * M0;
                 const float tm = 1.52587890625e-05f * S;  // 2^-16 S
                 // 2^-40 < M0 < 2^30: S and the thresholds are normal fp32 numbers, the error bounds hold; not a sliver
-                const bool tri_ok = a.use_filter && (M0 < 1073741824.0f) && (M0 > 9.094947017729282e-13f) &&
+                const bool tri_ok = (a.use_filter & 1) && (M0 < 1073741824.0f) && (M0 > 9.094947017729282e-13f) &&
                                     (fabsf(D) >= 0.00390625f * S);
                 const bool dpos = D > 0.0f;
                 // one flat loop over the window's pixels (not y / x nests): the compiler keeps it rolled, which holds the
@@ -1332,7 +1349,7 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     a.im_gray = im_gray; a.net_in = net_in; a.depth_img = depth_img;
     a.wm1 = (float)(W - 1);
     a.hm1 = (float)(H - 1);
-    a.use_filter = env_int("FR_EMIT_FILTER", 1);
+    a.use_filter = env_int("FR_EMIT_FILTER", 3);   // bit 0: certified fp32 inside test, bit 1: single-pixel pre-cull in phase A
     a.rows_magic = g.rows > 1 ? (uint32_t)((0x100000000ull + (unsigned)g.rows - 1) / (unsigned)g.rows) : 0u;
 
     const bool binned = g.binned_ok && ntri > 0 && !env_is("FR_RENDER_IMPL", "scan");
