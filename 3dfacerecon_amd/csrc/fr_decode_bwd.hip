@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256) void bwd_prepass_kernel(BwdArgs a) {
 // ---- the reduction over vertices on the matrix cores -------------------------------------------------------------------
 // D^T[coeff][batch] += sum_k basis[row k][coeff] * dv[row k][batch]:  A operand = basis^T (lane l: row r0+(l>>4),
 // coefficient c0+(l&15)), B operand = dv (lane l: row r0+(l>>4), batch 16*mb+(l&15)).
+// NB: live 16-column blocks of this pass (1..4): dead blocks cost neither MFMAs nor slab stores -- at the 32 faces per
+// GPU of the reference's train loop that is half of the matrix work.  The row loop is unrolled by two k-steps with both
+// steps' operands requested before the first MFMA issues.
+template <int NB>
 __global__ __launch_bounds__(BW_WAVES * 64) void bwd_gemm_kernel(BwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long rows = 3ll * a.N;
@@ -171,32 +175,38 @@ __global__ __launch_bounds__(BW_WAVES * 64) void bwd_gemm_kernel(BwdArgs a) {
             src[t] = a.pc_exp; stride[t] = a.ne; col[t] = (cb - GSB) * 16 + jn; cok[t] = col[t] < a.ne;
         }
     }
-    f32x4 acc[BW_CB][4];
+    f32x4 acc[BW_CB][NB];
 #pragma unroll
     for (int t = 0; t < BW_CB; t++)
 #pragma unroll
-        for (int mb = 0; mb < 4; mb++) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (long long r = r_begin; r < r_end; r += 4) {
-        const long long rr = r + kq;
-        const bool rok = rr < r_end;
-        const float4 dv = rok ? a.dvT4[(size_t)rr * 16 + jn] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float av[BW_CB];
+        for (int mb = 0; mb < NB; mb++) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto bsel = [](const float4& v, int mb) { return mb == 0 ? v.x : mb == 1 ? v.y : mb == 2 ? v.z : v.w; };
+    constexpr int UN = 2;   // k-steps (of 4 rows) per trip; the chains stay in row order
+    for (long long r = r_begin; r < r_end; r += 4 * UN) {
+        float4 dv[UN];
+        float av[UN][BW_CB];
 #pragma unroll
-        for (int t = 0; t < BW_CB; t++) av[t] = (rok && cok[t]) ? src[t][(size_t)rr * stride[t] + col[t]] : 0.f;
+        for (int u = 0; u < UN; u++) {
+            const long long rr = r + 4 * u + kq;
+            const bool rok = rr < r_end;
+            dv[u] = rok ? a.dvT4[(size_t)rr * 16 + jn] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int t = 0; t < BW_CB; t++) {
-            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], dv.x, acc[t][0], 0, 0, 0);
-            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], dv.y, acc[t][1], 0, 0, 0);
-            acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], dv.z, acc[t][2], 0, 0, 0);
-            acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], dv.w, acc[t][3], 0, 0, 0);
+            for (int t = 0; t < BW_CB; t++) av[u][t] = (rok && cok[t]) ? src[t][(size_t)rr * stride[t] + col[t]] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+#pragma unroll
+            for (int t = 0; t < BW_CB; t++)
+#pragma unroll
+                for (int mb = 0; mb < NB; mb++)
+                    acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t], bsel(dv[u], mb), acc[t][mb], 0, 0, 0);
     }
     // D^T tile: row (coefficient within block) = 4*(lane>>4) + reg, column (batch within block) = lane & 15
     float* slab = a.slab + (size_t)blockIdx.x * BW_MAXCOEF * 64;
 #pragma unroll
     for (int t = 0; t < BW_CB; t++)
 #pragma unroll
-        for (int mb = 0; mb < 4; mb++)
+        for (int mb = 0; mb < NB; mb++)
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) {
                 const int coef = (wave * BW_CB + t) * 16 + 4 * kq + rg;
@@ -316,7 +326,11 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
         a.b0 = b0;
         a.nbatch = min(B - b0, 64);
         hipLaunchKernelGGL(bwd_prepass_kernel, dim3(g.pre_blocks), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(bwd_gemm_kernel, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
+        const int nbt = (a.nbatch + 15) / 16;
+        if (nbt == 1) hipLaunchKernelGGL(bwd_gemm_kernel<1>, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
+        else if (nbt == 2) hipLaunchKernelGGL(bwd_gemm_kernel<2>, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
+        else if (nbt == 3) hipLaunchKernelGGL(bwd_gemm_kernel<3>, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
+        else hipLaunchKernelGGL(bwd_gemm_kernel<4>, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
         hipLaunchKernelGGL(bwd_reduce_kernel, dim3(4 + BW_MAXCOEF), dim3(RED_WAVES * 64), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Development probe: time of fr_decode_3dmm_backward (three kernels) through the autograd surface, full-size basis."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def pkg(n):
+    return importlib.import_module("3dfacerecon_amd." + n)
+
+
+synth, netm = pkg("utils.synth"), pkg("nets.network")
+A = synth.make_assets()
+for B in (16, 32, 64):
+    net = netm.FaceRecNet(mesh_data=A, batch_size=B, im_size=200, device="cuda:0")
+    P = torch.as_tensor(synth.sample_params_batch(B, im_size=200, beta=0.7), device="cuda:0").requires_grad_(True)
+    V = net.vertices_transform(P)
+    G = torch.randn_like(V)
+    def bwd():
+        P.grad = None
+        V.backward(G, retain_graph=True)
+    for _ in range(5):
+        bwd()
+    torch.cuda.synchronize()
+    ts = []
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            bwd()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 30 * 1e3)
+    print("B=%d decode backward: %s us" % (B, " ".join("%.1f" % t for t in ts)), flush=True)
