@@ -130,9 +130,8 @@ int fr_decode_set_arith(int mode) { return fr_decode_arith_set(mode); }
 int fr_decode_get_arith(void) { return fr_decode_arith_get(); }
 
 size_t fr_decode_backward_workspace_bytes(int B, int N, int n_shape, int n_exp) {
-    (void)n_shape; (void)n_exp;
-    if (B <= 0 || N <= 0) return 0;
-    return fr_decode_backward_workspace_impl(N);
+    if (B <= 0 || N <= 0 || n_shape < 0 || n_exp < 0) return 0;
+    return fr_decode_backward_workspace_impl(N, n_shape, n_exp);
 }
 
 int fr_decode_3dmm_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,

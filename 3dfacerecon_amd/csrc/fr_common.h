@@ -119,7 +119,7 @@ int fr_launch_decode_q(const float* params, const void* qimage, const float* R_o
                        int n_exp, float im_size, float* vertex_proj, int cus, hipStream_t stream);
 int fr_decode_arith_get();
 int fr_decode_arith_set(int mode);
-size_t fr_decode_backward_workspace_impl(int N);
+size_t fr_decode_backward_workspace_impl(int N, int ns, int ne);
 int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
                               const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N, int ns,
                               int ne, float im_size, float* grad_params, void* workspace, hipStream_t stream);

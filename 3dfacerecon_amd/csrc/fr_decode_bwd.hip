@@ -12,11 +12,12 @@
 //                       (LDS tile transpose so both the read of g and the write of dvT4 are coalesced), plus
 //                       per-workgroup partial sums for d t3d and d f;
 //   bwd_gemm_kernel     the [228 x 3N].[3N x 64] reduction on the matrix cores (exact-f32 v_mfma_f32_16x16x4_f32):
-//                       split over row chunks, one 5-wave workgroup per chunk, wave w owns coefficient blocks
-//                       3w..3w+2 (16 coefficients each; 13 shape blocks + 2 expression blocks), basis^T fragments
-//                       come straight from the reference-layout basis (64-byte row segments), dv fragments are one
-//                       dwordx4 per k-step shared through L1 by the five waves; partial [240 x 64] slabs go to
-//                       the workspace;
+//                       split over row chunks, one workgroup per chunk, wave w owns 64 coefficient slots (lane l of a
+//                       k-step loads FOUR consecutive coefficients of row l>>4 with one 16-byte request -- 256
+//                       contiguous bytes of the reference-layout row per 16 lanes -- and feeds them to four MFMAs,
+//                       element i to MFMA i, so MFMA i's 16 output rows are coefficients 4 m + i), dv fragments are
+//                       one dwordx4 per k-step shared through L1 by the waves; partial [slots x 64] slabs go to the
+//                       workspace;
 //   bwd_reduce_kernel   sums the slabs / partials in a fixed order and writes grad_params.
 #include "fr_common.h"
 
@@ -25,9 +26,10 @@ namespace fr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BW_PV = 64;        // vertices per prepass workgroup
-constexpr int BW_WAVES = 5;      // gemm waves per workgroup (15 coefficient blocks / 3)
-constexpr int BW_CB = 3;         // coefficient blocks per wave
-constexpr int BW_MAXCOEF = BW_WAVES * BW_CB * 16;  // 240 padded coefficients
+constexpr int BW_MAXWAVES = 8;   // gemm waves per workgroup: one per 64 coefficient slots (<= 512 slots)
+// coefficient slots: shape columns padded to a multiple of 4, then expression columns padded to a multiple of 4
+__host__ __device__ inline int bw_ns4(int ns) { return (ns + 3) & ~3; }
+__host__ __device__ inline int bw_waves(int ns, int ne) { return (bw_ns4(ns) + ((ne + 3) & ~3) + 63) / 64; }
 
 struct BwdArgs {
     const float* g;          // [B,3,N]
@@ -39,7 +41,7 @@ struct BwdArgs {
     float* grad_params;      // [B,nd]
     float4* dvT4;            // [3N][16] float4: dv[row][batch = 16*mb + j] at [row][j].mb
     float* pose_part;        // [prepass blocks][64][4]  (dt_x, dt_y, dt_z, sum (q-t).dq)
-    float* slab;             // [gemm blocks][240][64]
+    float* slab;             // [gemm blocks][64 * waves slots][64]
     int B, N, ns, ne, b0, nbatch;
     int pre_blocks, gemm_blocks, rows_per_block;
     float im_size;
@@ -101,39 +103,59 @@ __global__ __launch_bounds__(256) void bwd_prepass_kernel(BwdArgs a) {
     __syncthreads();
     const int p = blockIdx.x * BW_PV + lane;
     const bool pok = p < N;
-    // wave wv handles batch columns 16*wv .. 16*wv+15, lane = vertex: reads of g / vproj are 256-byte coalesced
-    for (int bq = 0; bq < 16; bq++) {
-        const int b = 16 * wv + bq;
-        float dq0 = 0.f, dq1 = 0.f, dq2 = 0.f, fs = 0.f;
-        if (pok && b < a.nbatch) {
+    // wave wv handles batch columns 16*wv .. 16*wv+15, lane = vertex: reads of g / vproj are 256-byte coalesced.  Four
+    // columns per trip: their 24 loads are requested (unconditionally, clamped) before anything is computed
+    const int pc = pok ? p : 0;
+    for (int bq0 = 0; bq0 < 16; bq0 += 4) {
+        float gq[4][3], vq[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) gq[u][c] = vq[u][c] = 0.f;
+        if (16 * wv + bq0 < a.nbatch)   // (wave-uniform: a trip whose four columns are all dead requests nothing)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int b = min(16 * wv + bq0 + u, a.nbatch - 1);
             const float* gb = a.g + (size_t)(a.b0 + b) * 3 * N;
             const float* vb = a.vproj + (size_t)(a.b0 + b) * 3 * N;
-            dq0 = gb[p];
-            dq1 = -gb[(size_t)N + p];
-            dq2 = gb[2 * (size_t)N + p];
-            // (q - t): q_0 = out_x, q_1 = (im - 1) - out_y, q_2 = out_z
-            const float q0 = vb[p] - Mt[b][9];
-            const float q1 = ((a.im_size - 1.0f) - vb[(size_t)N + p]) - Mt[b][10];
-            const float q2 = vb[2 * (size_t)N + p] - Mt[b][11];
-            fs = __builtin_fmaf(q2, dq2, __builtin_fmaf(q1, dq1, q0 * dq0));
-        }
-        const float* m = Mt[b];
-        const int bslot = (b & 15) * 4 + (b >> 4);
 #pragma unroll
-        for (int c = 0; c < 3; c++)
-            tile[c][lane][bslot] = __builtin_fmaf(m[6 + c], dq2, __builtin_fmaf(m[3 + c], dq1, m[c] * dq0));
-        // fixed-order wave reduction over the 64 vertices
-        float r0 = dq0, r1 = dq1, r2 = dq2, r3 = fs;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            r0 += __shfl_xor(r0, d);
-            r1 += __shfl_xor(r1, d);
-            r2 += __shfl_xor(r2, d);
-            r3 += __shfl_xor(r3, d);
+            for (int c = 0; c < 3; c++) {
+                gq[u][c] = gb[(size_t)c * N + pc];
+                vq[u][c] = vb[(size_t)c * N + pc];
+            }
         }
-        if (lane == 0) {
-            float* pp = a.pose_part + ((size_t)blockIdx.x * 64 + b) * 4;
-            pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3 * m[12];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int b = 16 * wv + bq0 + u;
+            float dq0 = 0.f, dq1 = 0.f, dq2 = 0.f, fs = 0.f;
+            if (pok && b < a.nbatch) {
+                dq0 = gq[u][0];
+                dq1 = -gq[u][1];
+                dq2 = gq[u][2];
+                // (q - t): q_0 = out_x, q_1 = (im - 1) - out_y, q_2 = out_z
+                const float q0 = vq[u][0] - Mt[b][9];
+                const float q1 = ((a.im_size - 1.0f) - vq[u][1]) - Mt[b][10];
+                const float q2 = vq[u][2] - Mt[b][11];
+                fs = __builtin_fmaf(q2, dq2, __builtin_fmaf(q1, dq1, q0 * dq0));
+            }
+            const float* m = Mt[b];
+            const int bslot = (b & 15) * 4 + (b >> 4);
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                tile[c][lane][bslot] = __builtin_fmaf(m[6 + c], dq2, __builtin_fmaf(m[3 + c], dq1, m[c] * dq0));
+            // fixed-order wave reduction over the 64 vertices
+            float r0 = dq0, r1 = dq1, r2 = dq2, r3 = fs;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                r0 += __shfl_xor(r0, d);
+                r1 += __shfl_xor(r1, d);
+                r2 += __shfl_xor(r2, d);
+                r3 += __shfl_xor(r3, d);
+            }
+            if (lane == 0) {
+                float* pp = a.pose_part + ((size_t)blockIdx.x * 64 + b) * 4;
+                pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3 * m[12];
+            }
         }
     }
     __syncthreads();
@@ -150,67 +172,80 @@ __global__ __launch_bounds__(256) void bwd_prepass_kernel(BwdArgs a) {
 
 // ---- the reduction over vertices on the matrix cores -------------------------------------------------------------------
 // D^T[coeff][batch] += sum_k basis[row k][coeff] * dv[row k][batch]:  A operand = basis^T (lane l: row r0+(l>>4),
-// coefficient c0+(l&15)), B operand = dv (lane l: row r0+(l>>4), batch 16*mb+(l&15)).
+// coefficient slot 4*(l&15)+i for MFMA i), B operand = dv (lane l: row r0+(l>>4), batch 16*mb+(l&15)).
 // NB: live 16-column blocks of this pass (1..4): dead blocks cost neither MFMAs nor slab stores -- at the 32 faces per
-// GPU of the reference's train loop that is half of the matrix work.  The row loop is unrolled by two k-steps with both
-// steps' operands requested before the first MFMA issues.
+// GPU of the reference's train loop that is half of the matrix work.  The row loop takes four k-steps per trip with all
+// their operands requested before the first MFMA issues; every accumulation chain stays in row order.
+typedef float f32x4u4 __attribute__((ext_vector_type(4), aligned(4)));
 template <int NB>
-__global__ __launch_bounds__(BW_WAVES * 64) void bwd_gemm_kernel(BwdArgs a) {
+__global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_gemm_kernel(BwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long rows = 3ll * a.N;
     const long long r_begin = (long long)blockIdx.x * a.rows_per_block;
     const long long r_end = min(rows, r_begin + a.rows_per_block);
-    const int GSB = (a.ns + 15) / 16;  // shape coefficient blocks
     const int kq = lane >> 4, jn = lane & 15;
-    // this wave's three coefficient blocks: source array, row stride, column of this lane, validity
-    const float* src[BW_CB];
-    int stride[BW_CB], col[BW_CB];
-    bool cok[BW_CB];
+    // this lane's four coefficient slots: source array, row stride, first column, live columns (0..4)
+    const int ns4 = bw_ns4(a.ns);
+    const int slot0 = 64 * wave + 4 * jn;
+    const bool in_shape = slot0 < ns4;
+    const float* src = in_shape ? a.pc_shape : a.pc_exp;
+    const int stride = in_shape ? a.ns : a.ne;
+    const int col0 = in_shape ? slot0 : slot0 - ns4;
+    const int live = max(0, min(4, stride - col0));
+    f32x4 acc[4][NB];
 #pragma unroll
-    for (int t = 0; t < BW_CB; t++) {
-        const int cb = wave * BW_CB + t;
-        if (cb < GSB) {
-            src[t] = a.pc_shape; stride[t] = a.ns; col[t] = cb * 16 + jn; cok[t] = col[t] < a.ns;
-        } else {
-            src[t] = a.pc_exp; stride[t] = a.ne; col[t] = (cb - GSB) * 16 + jn; cok[t] = col[t] < a.ne;
-        }
-    }
-    f32x4 acc[BW_CB][NB];
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int t = 0; t < BW_CB; t++)
-#pragma unroll
-        for (int mb = 0; mb < NB; mb++) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mb = 0; mb < NB; mb++) acc[i][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto bsel = [](const float4& v, int mb) { return mb == 0 ? v.x : mb == 1 ? v.y : mb == 2 ? v.z : v.w; };
-    constexpr int UN = 2;   // k-steps (of 4 rows) per trip; the chains stay in row order
-    for (long long r = r_begin; r < r_end; r += 4 * UN) {
-        float4 dv[UN];
-        float av[UN][BW_CB];
+    constexpr int UN = 4;   // k-steps (of 4 rows) per trip
+    auto request = [&](long long r, float4 (&dv)[UN], f32x4 (&av)[UN]) {
 #pragma unroll
         for (int u = 0; u < UN; u++) {
             const long long rr = r + 4 * u + kq;
             const bool rok = rr < r_end;
             dv[u] = rok ? a.dvT4[(size_t)rr * 16 + jn] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int t = 0; t < BW_CB; t++) av[u][t] = (rok && cok[t]) ? src[t][(size_t)rr * stride[t] + col[t]] : 0.f;
+            av[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (rok) {
+                const float* ptr = src + (size_t)rr * stride + col0;
+                if (live == 4) {
+                    av[u] = *reinterpret_cast<const f32x4u4*>(ptr);   // (rows are only 4-byte aligned: 199 columns)
+                } else {   // the array's last, partial quadruple: never read past the row
+                    if (live > 0) av[u][0] = ptr[0];
+                    if (live > 1) av[u][1] = ptr[1];
+                    if (live > 2) av[u][2] = ptr[2];
+                }
+            }
         }
+    };
+    auto consume = [&](const float4 (&dv)[UN], const f32x4 (&av)[UN]) {
 #pragma unroll
         for (int u = 0; u < UN; u++)
 #pragma unroll
-            for (int t = 0; t < BW_CB; t++)
+            for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int mb = 0; mb < NB; mb++)
-                    acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t], bsel(dv[u], mb), acc[t][mb], 0, 0, 0);
+                    acc[i][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bsel(dv[u], mb), acc[i][mb], 0, 0, 0);
+    };
+    // (a second operand set, requested one trip ahead, measured no faster: 44.3 / 71.4 us against 45.1 / 68.0 us at
+    // 32 / 64 faces, at 176 instead of 110 VGPRs)
+    for (long long r = r_begin; r < r_end; r += 4 * UN) {
+        float4 dv[UN];
+        f32x4 av[UN];
+        request(r, dv, av);
+        consume(dv, av);
     }
-    // D^T tile: row (coefficient within block) = 4*(lane>>4) + reg, column (batch within block) = lane & 15
-    float* slab = a.slab + (size_t)blockIdx.x * BW_MAXCOEF * 64;
+    // D^T tile of MFMA i: row m = 4*(lane>>4) + reg is coefficient slot 64*wave + 4*m + i, column (batch within block) = lane & 15
+    const int nslots = 64 * (int)(blockDim.x >> 6);
+    float* slab = a.slab + (size_t)blockIdx.x * nslots * 64;
 #pragma unroll
-    for (int t = 0; t < BW_CB; t++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int mb = 0; mb < NB; mb++)
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) {
-                const int coef = (wave * BW_CB + t) * 16 + 4 * kq + rg;
-                slab[(size_t)coef * 64 + 16 * mb + jn] = acc[t][mb][rg];
+                const int slot = 64 * wave + 4 * (4 * kq + rg) + i;
+                slab[(size_t)slot * 64 + 16 * mb + jn] = acc[i][mb][rg];
             }
 }
 
@@ -223,7 +258,7 @@ constexpr int RED_WAVES = 16;
 __global__ __launch_bounds__(RED_WAVES * 64) void bwd_reduce_kernel(BwdArgs a) {
     __shared__ float part[RED_WAVES][64];
     const int nd = FR_N_POSE + a.ns + a.ne;
-    const int GSB = (a.ns + 15) / 16;
+    const int nslots = 64 * bw_waves(a.ns, a.ne);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int what = blockIdx.x, b = lane;  // i = what * 64 + b
     const float* src;
@@ -235,7 +270,7 @@ __global__ __launch_bounds__(RED_WAVES * 64) void bwd_reduce_kernel(BwdArgs a) {
         nk = a.pre_blocks;
     } else {
         src = a.slab + (size_t)(what - 4) * 64 + b;
-        kstride = (size_t)BW_MAXCOEF * 64;
+        kstride = (size_t)nslots * 64;
         nk = a.gemm_blocks;
     }
     const int per = (nk + RED_WAVES - 1) / RED_WAVES;
@@ -244,6 +279,15 @@ __global__ __launch_bounds__(RED_WAVES * 64) void bwd_reduce_kernel(BwdArgs a) {
 #pragma unroll
     for (int u = 0; u < 8; u++) s[u] = 0.f;
     int k = k0;
+    for (; k + 16 <= k1; k += 16) {   // sixteen loads in flight; s[u] still receives k0+u, k0+u+8, ... in that order
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = src[(size_t)(k + u) * kstride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s[u] += v[u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s[u] += v[8 + u];
+    }
     for (; k + 8 <= k1; k += 8) {
         float v[8];
 #pragma unroll
@@ -265,12 +309,11 @@ __global__ __launch_bounds__(RED_WAVES * 64) void bwd_reduce_kernel(BwdArgs a) {
     } else if (what == 3) {
         gp[6] = tot;
     } else {
-        const int coef = what - 4;
-        const int cb = coef >> 4, cc = coef & 15;
-        if (cb < GSB) {
-            if (cb * 16 + cc < a.ns) gp[FR_N_POSE + cb * 16 + cc] = tot;
-        } else if ((cb - GSB) * 16 + cc < a.ne) {
-            gp[FR_N_POSE + a.ns + (cb - GSB) * 16 + cc] = tot;
+        const int slot = what - 4, ns4 = bw_ns4(a.ns);
+        if (slot < ns4) {
+            if (slot < a.ns) gp[FR_N_POSE + slot] = tot;
+        } else if (slot - ns4 < a.ne) {
+            gp[FR_N_POSE + a.ns + slot - ns4] = tot;
         }
     }
 }
@@ -279,7 +322,7 @@ struct BwdGeom {
     int pre_blocks, gemm_blocks, rows_per_block;
     size_t dv_bytes, pose_bytes, slab_bytes;
 };
-static BwdGeom bwd_geom(int N) {
+static BwdGeom bwd_geom(int N, int ns = 199, int ne = 29) {
     BwdGeom g;
     g.pre_blocks = (N + BW_PV - 1) / BW_PV;
     const long long rows = 3ll * N;
@@ -291,15 +334,15 @@ static BwdGeom bwd_geom(int N) {
     g.gemm_blocks = (int)((rows + rpb - 1) / rpb);
     g.dv_bytes = (size_t)rows * 16 * sizeof(float4);
     g.pose_bytes = (((size_t)g.pre_blocks * 64 * 4 * sizeof(float)) + 15) & ~(size_t)15;
-    g.slab_bytes = (size_t)g.gemm_blocks * BW_MAXCOEF * 64 * sizeof(float);
+    g.slab_bytes = (size_t)g.gemm_blocks * 64 * bw_waves(ns, ne) * 64 * sizeof(float);
     return g;
 }
 
 }  // namespace fr
 
-size_t fr_decode_backward_workspace_impl(int N) {
+size_t fr_decode_backward_workspace_impl(int N, int ns, int ne) {
     if (N <= 0) return 0;
-    fr::BwdGeom g = fr::bwd_geom(N);
+    fr::BwdGeom g = fr::bwd_geom(N, ns, ne);
     return g.dv_bytes + g.pose_bytes + g.slab_bytes;
 }
 
@@ -311,8 +354,9 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
     const int nd = FR_N_POSE + ns + ne;
     if (N == 0) return hipMemsetAsync(grad_params, 0, (size_t)B * nd * sizeof(float), stream) == hipSuccess ? FR_OK
                                                                                                              : FR_ERR_LAUNCH;
-    if ((ns + 15) / 16 + (ne + 15) / 16 > BW_WAVES * BW_CB) return FR_ERR_UNSUPPORTED;  // > 240 padded coefficients
-    BwdGeom g = bwd_geom(N);
+    const int waves = bw_waves(ns, ne);
+    if (waves > BW_MAXWAVES) return FR_ERR_UNSUPPORTED;  // > 512 coefficient slots
+    BwdGeom g = bwd_geom(N, ns, ne);
     BwdArgs a;
     a.g = grad_vertex_proj; a.params = params; a.vproj = vertex_proj;
     a.pc_shape = pc_shape; a.pc_exp = pc_exp; a.R_override = R_override; a.grad_params = grad_params;
@@ -327,11 +371,14 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
         a.nbatch = min(B - b0, 64);
         hipLaunchKernelGGL(bwd_prepass_kernel, dim3(g.pre_blocks), dim3(256), 0, stream, a);
         const int nbt = (a.nbatch + 15) / 16;
-        if (nbt == 1) hipLaunchKernelGGL(bwd_gemm_kernel<1>, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
-        else if (nbt == 2) hipLaunchKernelGGL(bwd_gemm_kernel<2>, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
-        else if (nbt == 3) hipLaunchKernelGGL(bwd_gemm_kernel<3>, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
-        else hipLaunchKernelGGL(bwd_gemm_kernel<4>, dim3(g.gemm_blocks), dim3(BW_WAVES * 64), 0, stream, a);
-        hipLaunchKernelGGL(bwd_reduce_kernel, dim3(4 + BW_MAXCOEF), dim3(RED_WAVES * 64), 0, stream, a);
+        if (waves > 0) {
+            const dim3 gb(waves * 64);
+            if (nbt == 1) hipLaunchKernelGGL(bwd_gemm_kernel<1>, dim3(g.gemm_blocks), gb, 0, stream, a);
+            else if (nbt == 2) hipLaunchKernelGGL(bwd_gemm_kernel<2>, dim3(g.gemm_blocks), gb, 0, stream, a);
+            else if (nbt == 3) hipLaunchKernelGGL(bwd_gemm_kernel<3>, dim3(g.gemm_blocks), gb, 0, stream, a);
+            else hipLaunchKernelGGL(bwd_gemm_kernel<4>, dim3(g.gemm_blocks), gb, 0, stream, a);
+        }
+        hipLaunchKernelGGL(bwd_reduce_kernel, dim3(4 + 64 * waves), dim3(RED_WAVES * 64), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }

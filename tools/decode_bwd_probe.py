@@ -15,7 +15,7 @@ def pkg(n):
 
 synth, netm = pkg("utils.synth"), pkg("nets.network")
 A = synth.make_assets()
-for B in (16, 32, 64):
+for B in [int(x) for x in os.environ.get("BWD_B", "16,32,64").split(",")]:
     net = netm.FaceRecNet(mesh_data=A, batch_size=B, im_size=200, device="cuda:0")
     P = torch.as_tensor(synth.sample_params_batch(B, im_size=200, beta=0.7), device="cuda:0").requires_grad_(True)
     V = net.vertices_transform(P)
