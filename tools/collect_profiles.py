@@ -15,8 +15,8 @@ P = os.path.join(ROOT, "profiles")
 
 
 def first(pattern):
-    f = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None   # the most recent run (gpurun merges every session's files into the same tree)
 
 
 def kernel_stats(name, out):
