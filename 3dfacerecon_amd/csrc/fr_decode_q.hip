@@ -88,10 +88,11 @@ __global__ __launch_bounds__(256) void q_colmax_kernel(const float* __restrict__
         if (m) atomicMax(&colmax[k], m);
     }
 }
-__global__ void q_ce_kernel(const unsigned* __restrict__ colmax, int K, int KP, int* __restrict__ ce) {
+// (in place: the header's ce[] slots first collect the column maxima, then each thread turns its own slot into the exponent)
+__global__ void q_ce_kernel(int K, int KP, int* ce) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= KP) return;
-    const unsigned m = k < K ? colmax[k] : 0u;
+    const unsigned m = k < K ? (unsigned)ce[k] : 0u;
     ce[k] = m ? q_exp_of((double)__uint_as_float(m)) : 0;
 }
 // per-vertex payload: mu and the three row exponents
@@ -523,21 +524,6 @@ size_t fr_packed_q_bytes(int N, int n_shape, int n_exp) {
     return qs.hdr_bytes + (size_t)tiles_of(N) * qs.tile_bytes + 1024;   // + slack: the last short fragment's over-read
 }
 
-static unsigned* q_colmax_scratch(int K) {  // per-device scratch for the column maxima (pack is a one-time operation)
-    static unsigned* buf[64];
-    static int cap[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (cap[dev] < K) {
-        if (buf[dev]) (void)hipFree(buf[dev]);
-        buf[dev] = nullptr;
-        cap[dev] = 0;
-        if (hipMalloc(&buf[dev], sizeof(unsigned) * (size_t)(K + 64)) != hipSuccess) return nullptr;
-        cap[dev] = K + 64;
-    }
-    return buf[dev];
-}
-
 // Per-(device, stream) staging buffer of the decode (68 KiB for the model's shape), allocated on first use and kept:
 // launches on one stream are ordered, so its passes can share one buffer; different streams must not.
 static char* q_stage_scratch(hipStream_t stream, size_t bytes) {
@@ -573,13 +559,11 @@ int fr_launch_pack_q(const float* mu, const float* pc_shape, const float* pc_exp
     int* ce = reinterpret_cast<int*>(qimage);
     char* tb = reinterpret_cast<char*>(qimage) + qs.hdr_bytes;
     const int KP = qs.S * 64;
-    unsigned* colmax = q_colmax_scratch(KP);
-    if (!colmax) return FR_ERR_LAUNCH;
-    if (hipMemsetAsync(colmax, 0, sizeof(unsigned) * KP, stream) != hipSuccess) return FR_ERR_LAUNCH;
     if (hipMemsetAsync(qimage, 0, fr_packed_q_bytes(N, n_shape, n_exp), stream) != hipSuccess) return FR_ERR_LAUNCH;
-    if (qs.K > 0)
-        hipLaunchKernelGGL(q_colmax_kernel, dim3(1024), dim3(256), 0, stream, pc_shape, pc_exp, N, n_shape, n_exp, colmax);
-    hipLaunchKernelGGL(q_ce_kernel, dim3((KP + 255) / 256), dim3(256), 0, stream, colmax, qs.K, KP, ce);
+    if (qs.K > 0)   // the column maxima are collected in the header's own ce[] slots (no scratch allocation)
+        hipLaunchKernelGGL(q_colmax_kernel, dim3(1024), dim3(256), 0, stream, pc_shape, pc_exp, N, n_shape, n_exp,
+                           reinterpret_cast<unsigned*>(ce));
+    hipLaunchKernelGGL(q_ce_kernel, dim3((KP + 255) / 256), dim3(256), 0, stream, qs.K, KP, ce);
     const long long NP = (long long)tiles_of(N) * TILE_V;
     hipLaunchKernelGGL(q_payload_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, mu, pc_shape, pc_exp, N,
                        n_shape, n_exp, ce, tb, qs);

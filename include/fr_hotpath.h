@@ -8,7 +8,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (outputs and workspace included); the library
- *     allocates nothing and never synchronises with the host;
+ *     allocates nothing (one exception: selecting FR_DECODE_ARITH_Q30 makes the library keep a 68 KiB staging buffer per
+ *     (device, stream), allocated on first use) and never synchronises with the host;
  *   - `hip_stream` is a hipStream_t (NULL = the default stream); all work is enqueued on it, in order;
  *   - return value: FR_OK (0) or a negative FR_ERR_* code (never swallowed, unlike the reference's
  *     printf-and-return at render_depth_op.cu.cc:290-295); fr_strerror() names it;
