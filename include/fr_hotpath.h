@@ -129,7 +129,7 @@ int fr_decode_pack_basis(const float* mu, const float* pc_shape, const float* pc
  *       quantised to 31 bits against power-of-two row / column scales (int8 matrix cores, 16 digit products): the
  *       correctly rounded fp32 value of the real-number blend in > 99 % of the cases (half the f32 chain's mean error);
  *       a non-finite parameter makes the face's vertices NaN.  n_shape + n_exp above 512 falls back to F32.  Measured
- *       6 % slower than F32 inside the 64-face pipeline, hence not the default.
+ *       2-11 % slower than F32 inside the 64-face pipeline, hence not the default.
  * Both are restated on the CPU in oracle/fr_oracle.c and the kernels are held to them bit for bit.  The choice is a
  * process-wide setting (initial value from the environment variable FR_DECODE_ARITH = "f32" | "q30"). */
 #define FR_DECODE_ARITH_Q30 0
