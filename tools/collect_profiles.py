@@ -39,6 +39,12 @@ for j in ("bench", "bench_k20", "bench_graph", "bench_q30"):
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.json" % (tag, j)))
 kernel_stats("prof_bench", "%s_kernel_stats.csv" % tag)
+# the bench line printed by the SAME process the kernel stats come from (profiled: lower clocks, per-launch overhead)
+f = os.path.join(src, "prof_bench.log")
+if os.path.exists(f):
+    lines = [l for l in open(f, errors="replace") if l.startswith("{") and '"metric"' in l]
+    if lines:
+        open(os.path.join(P, "%s_bench_under_rocprofv3.json" % tag), "w").write(lines[-1])
 callers = {}
 for cfg, js in (("c3", "config3_fwd"), ("c4", "config4_train_shard"), ("c5", "config5_fine448_shard")):
     rec = {}
