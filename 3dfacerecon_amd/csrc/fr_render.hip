@@ -520,10 +520,10 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             surv[u] = valid[u] && (fx0 >= 0.0f) && (fy0 >= 0.0f) && (fx1 <= a.wm1) && (fy1 <= a.hm1) && !(fx1 < fx0) &&
                       !(fy1 < fy0);
             single[u] = (fx0 == fx1) && (fy0 == fy1);
-            // A bbox with a single pixel centre (78 % of the survivors on a sub-pixel mesh) misses that centre about half
-            // of the time.  The certified fp32 inside test of phase B (same expressions, same pixel, see there) is cheap
+            // A bbox with a single pixel centre (78 % of the survivors on a sub-pixel mesh) misses that centre 70 % of the
+            // time.  The certified fp32 inside test of phase B (same expressions, same pixel, see there) is cheap
             // enough to run here, on the sparse lanes: a triangle it certifies as a MISS can emit nothing and is dropped
-            // before the compaction, so that phase B runs on ~40 % fewer lanes; anything it cannot certify stays.  (Flagging
+            // before the compaction, so that phase B runs on less than half the lanes; anything it cannot certify stays.  (Flagging
             // the certified HITS so that phase B skips their test measured no further gain.)
             if ((a.use_filter & 2) && surv[u] && single[u]) {
                 const float v0x = x3[u] - x1[u], v0y = y3[u] - y1[u], v1x = x2[u] - x1[u], v1y = y2[u] - y1[u];
