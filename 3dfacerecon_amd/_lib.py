@@ -36,8 +36,16 @@ def _hipcc():
     return "hipcc"
 
 
+def sources_present():
+    """False for a binary-only deployment (the .so shipped without csrc/ or include/)."""
+    return all(os.path.exists(d) for d in [os.path.join(_CSRC, s) for s in SOURCES] + HEADERS)
+
+
 def src_hash():
-    """sha256 over the kernel sources, the headers and the compile flags (16 hex digits): the identity of a build."""
+    """sha256 over the kernel sources, the headers and the compile flags (16 hex digits): the identity of a build.
+    None when the sources are not in the tree (binary-only deployment: nothing to compare the library with)."""
+    if not sources_present():
+        return None
     h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
     for d in [os.path.join(_CSRC, s) for s in SOURCES] + HEADERS:
         with open(d, "rb") as f:
@@ -46,17 +54,34 @@ def src_hash():
 
 
 def _built_hash():
+    """The source hash the existing .so was built from: its sidecar file, or -- when the sidecar did not travel with the
+    binary -- the hash embedded in the binary itself (the `src=` field of fr_version(), found by scanning the file: the
+    library is not loaded to ask it)."""
     try:
         with open(LIB_PATH + ".srchash") as f:
             return f.read().strip()
     except OSError:
+        pass
+    try:
+        with open(LIB_PATH, "rb") as f:
+            blob = f.read()
+    except OSError:
         return None
+    tag = b"(gfx950) src="
+    i = blob.find(tag)
+    if i < 0:
+        return None
+    return blob[i + len(tag):i + len(tag) + 16].decode("ascii", "replace")
 
 
 def is_stale():
     """True when libfr_hotpath.so is missing or was built from other sources than the ones in the tree (content hash,
-    not mtimes: the .so travels to the GPU box in a snapshot whose timestamps mean nothing)."""
-    return not os.path.exists(LIB_PATH) or _built_hash() != src_hash()
+    not mtimes: the .so travels to the GPU box in a snapshot whose timestamps mean nothing).  Without sources in the
+    tree an existing library is taken as it is."""
+    if not os.path.exists(LIB_PATH):
+        return True
+    want = src_hash()
+    return want is not None and _built_hash() != want
 
 
 def compile(force=False, verbose=False):
@@ -68,14 +93,17 @@ def compile(force=False, verbose=False):
         raise RuntimeError("fr_hotpath: %s is %s and hipcc is not available to rebuild it -- there is no CPU fallback"
                            % (LIB_PATH, "stale" if os.path.exists(LIB_PATH) else "missing"))
     want = src_hash()
+    if want is None:
+        raise RuntimeError("fr_hotpath: %s is missing and the kernel sources are not in the tree" % LIB_PATH)
     tmp = LIB_PATH + ".tmp%d" % os.getpid()
     cmd = [hipcc] + HIPCC_FLAGS + ['-DFR_SRC_HASH="%s"' % want, "-o", tmp] + [os.path.join(_CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)
-    os.replace(tmp, LIB_PATH)
-    with open(LIB_PATH + ".srchash", "w") as f:
+    with open(LIB_PATH + ".srchash.tmp%d" % os.getpid(), "w") as f:
         f.write(want + "\n")
+    os.replace(tmp, LIB_PATH)
+    os.replace(LIB_PATH + ".srchash.tmp%d" % os.getpid(), LIB_PATH + ".srchash")
     return LIB_PATH
 
 
@@ -106,10 +134,18 @@ def _bind(L):
     L.fr_decode_pack_basis.restype = _i
     L.fr_decode_3dmm.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp]
     L.fr_decode_3dmm.restype = _i
-    L.fr_decode_set_arith.argtypes = [_i]
-    L.fr_decode_set_arith.restype = _i
-    L.fr_decode_get_arith.argtypes = []
-    L.fr_decode_get_arith.restype = _i
+    L.fr_decode_q30_image_bytes.argtypes = [_i, _i, _i]
+    L.fr_decode_q30_image_bytes.restype = ctypes.c_size_t
+    L.fr_decode_q30_pack.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
+    L.fr_decode_q30_pack.restype = _i
+    L.fr_decode_q30_workspace_bytes.argtypes = [_i, _i]
+    L.fr_decode_q30_workspace_bytes.restype = ctypes.c_size_t
+    L.fr_decode_3dmm_q30.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]
+    L.fr_decode_3dmm_q30.restype = _i
+    L.fr_set_option.argtypes = [ctypes.c_char_p, _i]
+    L.fr_set_option.restype = _i
+    L.fr_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    L.fr_get_option.restype = _i
     L.fr_decode_backward_workspace_bytes.argtypes = [_i, _i, _i, _i]
     L.fr_decode_backward_workspace_bytes.restype = ctypes.c_size_t
     L.fr_decode_3dmm_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp,
@@ -126,8 +162,8 @@ EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_r
            "fr_render_depth_backward", "fr_decode_packed_basis_bytes", "fr_decode_pack_basis", "fr_decode_3dmm",
            "fr_decode_backward_workspace_bytes", "fr_decode_3dmm_backward", "fr_rendering_layer_forward",
            "fr_render_depth_forward_phases", "fr_debug_render_geom", "fr_debug_div3_sweep",
-           "fr_render_depth_backward_workspace_bytes", "fr_render_depth_backward_ws", "fr_decode_set_arith",
-           "fr_decode_get_arith"]
+           "fr_render_depth_backward_workspace_bytes", "fr_render_depth_backward_ws", "fr_set_option", "fr_get_option",
+           "fr_decode_q30_image_bytes", "fr_decode_q30_pack", "fr_decode_q30_workspace_bytes", "fr_decode_3dmm_q30"]
 
 
 def lib():
@@ -147,11 +183,64 @@ def lib():
                     raise RuntimeError("fr_hotpath: cannot load %s (%s); run compile() -- there is no CPU fallback"
                                        % (LIB_PATH, e))
                 want = src_hash()
-                if want.encode() not in L.fr_version():
+                if want is not None and want.encode() not in L.fr_version():
                     raise RuntimeError("fr_hotpath: %s reports %r but the sources hash to %s: stale binary refused"
                                        % (LIB_PATH, L.fr_version(), want))
                 _lib = L
     return _lib
+
+
+# ---- host-side choices --------------------------------------------------------------------------------------------
+DECODE_ARITH_Q30, DECODE_ARITH_F32 = 0, 1
+_decode_arith = None
+
+
+def decode_arith():
+    """Which written definition of the basis blend the Python callers (FaceRecNet.vertices_transform, DecodeRenderPlan)
+    use: DECODE_ARITH_F32 (default: fr_decode_3dmm, the k-ordered fmaf chain) or DECODE_ARITH_Q30 (fr_decode_3dmm_q30,
+    the frozen exact-fixed-point experiment; its image and workspace are built on first use).  Process-wide; the initial
+    value comes from the environment variable FR_DECODE_ARITH = "f32" | "q30", read once."""
+    global _decode_arith
+    if _decode_arith is None:
+        _decode_arith = DECODE_ARITH_Q30 if os.environ.get("FR_DECODE_ARITH") == "q30" else DECODE_ARITH_F32
+    return _decode_arith
+
+
+def set_decode_arith(mode):
+    global _decode_arith
+    if mode not in (DECODE_ARITH_Q30, DECODE_ARITH_F32):
+        raise ValueError("decode arithmetic must be DECODE_ARITH_F32 or DECODE_ARITH_Q30")
+    _decode_arith = mode
+
+
+def set_option(name, value):
+    """fr_set_option: a launcher knob by its FR_* name (the environment is only read once, at the first launch)."""
+    check(lib().fr_set_option(name.encode(), int(value)), "fr_set_option(%s)" % name)
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(lib().fr_get_option(name.encode(), ctypes.byref(v)), "fr_get_option(%s)" % name)
+    return v.value
+
+
+class options:
+    """Context manager for A/B runs and tests: `with options(FR_EMIT_FILTER=0): ...` sets the knobs and restores them."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def check(rc, what):

@@ -1,14 +1,68 @@
 // extern "C" entry points declared in include/fr_hotpath.h: argument validation (the OP_REQUIRES checks of
 // render_depth_op.cc:408-418, 498-503 re-stated) and dispatch to the gfx950 launchers.
+#include <atomic>
+#include <mutex>
+
 #include "fr_common.h"
 
+// ---- option table: environment read once, fr_set_option afterwards ------------------------------------------------------
+namespace {
+struct OptDesc {
+    const char* name;
+    int dflt;
+    const char* word;  // a non-numeric spelling of value 1 ("loop", "scan"), or null
+};
+const OptDesc kOpts[fr::OPT_COUNT] = {
+    {"FR_DECODE_IMPL", 0, "loop"}, {"FR_DECODE_WIDE", 1, nullptr}, {"FR_DECODE_NBW", 0, nullptr},
+    {"FR_DECODE_WAVES", 16, nullptr}, {"FR_DECODE_NT", 1, nullptr}, {"FR_RESOLVE_OPT", 1, nullptr},
+    {"FR_EMIT_FILTER", 3, nullptr}, {"FR_RENDER_IMPL", 0, "scan"}, {"FR_RESOLVE_BLOCK", 0, nullptr},
+    {"FR_RENDER_ROWS", 0, nullptr},
+};
+std::atomic<int> g_opt[fr::OPT_COUNT];
+std::once_flag g_opt_once;
+void opts_init() {
+    for (int i = 0; i < fr::OPT_COUNT; i++) {
+        int v = kOpts[i].dflt;
+        const char* e = getenv(kOpts[i].name);
+        if (e && *e) v = (kOpts[i].word && !strcmp(e, kOpts[i].word)) ? 1 : atoi(e);
+        g_opt[i].store(v, std::memory_order_relaxed);
+    }
+}
+int opt_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < fr::OPT_COUNT; i++)
+        if (!strcmp(name, kOpts[i].name)) return i;
+    return -1;
+}
+}  // namespace
+
+int fr::opt(fr::Opt o) {
+    std::call_once(g_opt_once, opts_init);
+    return g_opt[o].load(std::memory_order_relaxed);
+}
+
 extern "C" {
+
+int fr_set_option(const char* name, int value) {
+    const int i = opt_index(name);
+    if (i < 0) return FR_ERR_INVALID_ARG;
+    std::call_once(g_opt_once, opts_init);
+    g_opt[i].store(value, std::memory_order_relaxed);
+    return FR_OK;
+}
+
+int fr_get_option(const char* name, int* value) {
+    const int i = opt_index(name);
+    if (i < 0 || !value) return FR_ERR_INVALID_ARG;
+    *value = fr::opt((fr::Opt)i);
+    return FR_OK;
+}
 
 #ifndef FR_SRC_HASH
 #define FR_SRC_HASH "unhashed"
 #endif
 // the build identity: _lib.py refuses a library whose source hash differs from the tree's
-const char* fr_version(void) { return "fr_hotpath 0.2 (gfx950) src=" FR_SRC_HASH; }
+const char* fr_version(void) { return "fr_hotpath 0.3 (gfx950) src=" FR_SRC_HASH; }
 
 const char* fr_strerror(int code) {
     switch (code) {
@@ -126,8 +180,40 @@ int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R
                             (hipStream_t)hip_stream);
 }
 
-int fr_decode_set_arith(int mode) { return fr_decode_arith_set(mode); }
-int fr_decode_get_arith(void) { return fr_decode_arith_get(); }
+// ---- opt-in Q30 arithmetic: its own image, its own entry point, caller-owned staging workspace ----------------------------
+size_t fr_decode_q30_image_bytes(int N, int n_shape, int n_exp) {
+    if (N < 0 || n_shape < 0 || n_exp < 0 || !fr_decode_q_supported(n_shape, n_exp)) return 0;
+    return fr_packed_q_bytes(N, n_shape, n_exp);
+}
+
+int fr_decode_q30_pack(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
+                       void* qimage, size_t qimage_bytes, void* hip_stream) {
+    if (N < 0 || n_shape < 0 || n_exp < 0) return FR_ERR_INVALID_ARG;
+    if (!fr_decode_q_supported(n_shape, n_exp)) return FR_ERR_UNSUPPORTED;
+    if (qimage_bytes < fr_packed_q_bytes(N, n_shape, n_exp)) return FR_ERR_WORKSPACE;
+    if (N == 0) return FR_OK;
+    if (!mu || !qimage || (n_shape > 0 && !pc_shape) || (n_exp > 0 && !pc_exp)) return FR_ERR_INVALID_ARG;
+    if (((uintptr_t)qimage & 255) != 0) return FR_ERR_INVALID_ARG;
+    return fr_launch_pack_q(mu, pc_shape, pc_exp, N, n_shape, n_exp, qimage, (hipStream_t)hip_stream);
+}
+
+size_t fr_decode_q30_workspace_bytes(int n_shape, int n_exp) {
+    if (n_shape < 0 || n_exp < 0) return 0;
+    return fr_decode_q_workspace_bytes_impl(n_shape, n_exp);
+}
+
+int fr_decode_3dmm_q30(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
+                       int n_exp, float im_size, float* vertex_proj, void* workspace, size_t ws_bytes, void* hip_stream) {
+    if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0) return FR_ERR_INVALID_ARG;
+    if (!fr_decode_q_supported(n_shape, n_exp)) return FR_ERR_UNSUPPORTED;
+    if ((size_t)B * N == 0) return FR_OK;
+    if (!params || !qimage || !vertex_proj) return FR_ERR_INVALID_ARG;
+    if (((uintptr_t)qimage & 255) != 0) return FR_ERR_INVALID_ARG;
+    if (!workspace || ws_bytes < fr_decode_q_workspace_bytes_impl(n_shape, n_exp) || ((uintptr_t)workspace & 15))
+        return FR_ERR_WORKSPACE;
+    return fr_launch_decode_q(params, qimage, R_override, B, N, n_shape, n_exp, im_size, vertex_proj, workspace, ws_bytes,
+                              (hipStream_t)hip_stream);
+}
 
 size_t fr_decode_backward_workspace_bytes(int B, int N, int n_shape, int n_exp) {
     if (B <= 0 || N <= 0 || n_shape < 0 || n_exp < 0) return 0;

@@ -91,6 +91,25 @@ inline hipError_t fr_allow_full_lds(const void* kernel, unsigned char* done /*[6
     return e;
 }
 
+// Tuning / A-B knobs of the launchers.  Each has an initial value taken ONCE per process from its environment variable
+// (first use of any knob) and can be changed afterwards through fr_set_option() only: the launch path never calls getenv.
+namespace fr {
+enum Opt {
+    OPT_DECODE_IMPL,    // FR_DECODE_IMPL    0 = ring schedule for the model's basis shape (default), 1 ("loop") = generic kernel
+    OPT_DECODE_WIDE,    // FR_DECODE_WIDE    1 = 128-column passes for batches above 64 (default), 0 = off
+    OPT_DECODE_NBW,     // FR_DECODE_NBW     0 = auto, 1 / 4 = column blocks per work item
+    OPT_DECODE_WAVES,   // FR_DECODE_WAVES   16 (default) or 8 waves per decode workgroup
+    OPT_DECODE_NT,      // FR_DECODE_NT      1 = non-temporal basis stream (default), 0 = default cache policy
+    OPT_RESOLVE_OPT,    // FR_RESOLVE_OPT    1 = single-trip bins keep records in registers (default), 0 = two-pass resolver
+    OPT_EMIT_FILTER,    // FR_EMIT_FILTER    bit 0: certified fp32 inside test, bit 1: single-pixel pre-cull (default 3)
+    OPT_RENDER_IMPL,    // FR_RENDER_IMPL    0 = binned rasteriser (default), 1 ("scan") = strip-scan fallback
+    OPT_RESOLVE_BLOCK,  // FR_RESOLVE_BLOCK  0 = auto, 256 / 512 / 1024 threads per resolver workgroup
+    OPT_RENDER_ROWS,    // FR_RENDER_ROWS    0 = auto, > 0 = rows per screen strip
+    OPT_COUNT
+};
+int opt(Opt o);
+}  // namespace fr
+
 // host-side launchers implemented in the .hip files
 int fr_launch_render_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                              int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
@@ -116,9 +135,9 @@ bool fr_decode_q_supported(int n_shape, int n_exp);
 int fr_launch_pack_q(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
                      void* qimage, hipStream_t stream);
 int fr_launch_decode_q(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
-                       int n_exp, float im_size, float* vertex_proj, int cus, hipStream_t stream);
-int fr_decode_arith_get();
-int fr_decode_arith_set(int mode);
+                       int n_exp, float im_size, float* vertex_proj, void* workspace, size_t ws_bytes, hipStream_t stream);
+size_t fr_decode_q_workspace_bytes_impl(int n_shape, int n_exp);
+int fr_device_cu_count();
 size_t fr_decode_backward_workspace_impl(int N, int ns, int ne);
 int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
                               const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N, int ns,

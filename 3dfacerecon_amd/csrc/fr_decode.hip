@@ -283,9 +283,19 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
 // unrolled straight-line code with no cursor branches.  The requests are inline asm so that the compiler can neither
 // reorder them nor drain them with its own vmcnt(0); the only waits are the counted s_waitcnt vmcnt(R-1) on the oldest
 // slot (FR_RING_WAIT ties the slot register to the wait).
-#ifndef FR_PROBE_DECODE
-#define FR_PROBE_DECODE 0  // development probes (tools/decode_probe.hip): 1 = no MFMA, 2 = requests hit 256 tiles, 4 = no prologue, 8 = no A requests, 16 = no LDS B reads, 32 = (almost) no stores
-#endif
+// Development hooks: the product instantiates the kernel with NoProbe only (every hook is an empty inline or a
+// compile-time-false branch); tools/decode_probe.hip supplies policies with ablation bits
+// (1 = no MFMA, 2 = requests hit 256 tiles, 4 = no prologue, 8 = no A requests, 16 = no LDS B reads, 32 = (almost) no
+// stores) and in-kernel s_memtime stamps.
+struct NoProbe {
+    static constexpr int bits = 0;
+    __device__ __forceinline__ void begin() {}
+    template <int ID> __device__ __forceinline__ void stamp() {}
+    __device__ __forceinline__ void item_begin() {}
+    __device__ __forceinline__ void item_mfma_done() {}
+    __device__ __forceinline__ void item_end() {}
+    __device__ __forceinline__ void finish(int, int, int) {}
+};
 #define FR_RING_LD(dst, sbase, voff)                                                                   \
     {                                                                                                  \
         if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase)); \
@@ -303,9 +313,11 @@ __device__ __forceinline__ void ring_wait(f32x4& slot) {
 // leaves VGPRs free on purpose: the 8-wave form (WPE = 4: <= 128 VGPRs, half the register file) lets the render
 // kernels of the previous batch share the CU with the decode of the next one (pipeline.py, PipelinedPlan).
 // NT: the basis stream is requested with the non-temporal hint (read once per launch by one CU pair of waves).
-template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64, int WPE = DEC_WAVES / 4, bool NT = false>
+template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64, int WPE = DEC_WAVES / 4, bool NT = false, class PR = NoProbe>
 __global__ __launch_bounds__(DEC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void decode_ring_kernel(DecodeArgs a) {
+    PR pr;
+    pr.begin();
     constexpr int DEC_BLOCK = DEC_WAVES * 64;
     constexpr int G = GS + GE;
     constexpr int F = 3 * (G + 1);  // fragments per item
@@ -338,11 +350,15 @@ void decode_ring_kernel(DecodeArgs a) {
     constexpr size_t tile_bytes = (size_t)G * 3 * 1024;
 
     f32x4 ring[R];
+    if constexpr (PR::bits & 8) {
+#pragma unroll
+        for (int f = 0; f < R; f++) ring[f] = (f32x4){1.f, 2.f, 3.f, 4.f};
+    }
     // fragment f (0..F-1) of tile t
 #define FR_REQ(slot_, f_, t_)                                                                        \
     {                                                                                                \
         if ((f_) < 3 * G) {                                                                          \
-            const char* sb_ = Ab + (size_t)((FR_PROBE_DECODE & 2) ? (t_) & 255 : (t_)) * tile_bytes + (size_t)(f_) * 1024; \
+            const char* sb_ = Ab + (size_t)((PR::bits & 2) ? (t_) & 255 : (t_)) * tile_bytes + (size_t)(f_) * 1024; \
             FR_RING_LD(ring[slot_], sb_, voffA);                                                     \
         } else {                                                                                     \
             const char* sb_ = Mb + (size_t)(t_) * (3 * TILE_V * 4) + (size_t)((f_) - 3 * G) * (TILE_V * 4); \
@@ -356,10 +372,13 @@ void decode_ring_kernel(DecodeArgs a) {
 #pragma unroll
         for (int f = 0; f < R; f++) FR_REQ(f, f, t0c)
     }
-    if constexpr (!(FR_PROBE_DECODE & 4)) decode_prologue<NBW, DEC_BLOCK, MB>(a, smem, Mt, SC, GS, GE, half_floats, tid, nd, nbatch);
+    pr.template stamp<0>();
+    if constexpr (!(PR::bits & 4)) decode_prologue<NBW, DEC_BLOCK, MB>(a, smem, Mt, SC, GS, GE, half_floats, tid, nd, nbatch);
+    pr.template stamp<1>();
     if (tile0 >= tiles) {
 #pragma unroll
         for (int f = 0; f < R; f++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[f]));
+        pr.finish((int)blockIdx.x, wave, 0);
         return;
     }
     f32x4 c[3][NBW], sv[3][NBW];
@@ -375,15 +394,17 @@ void decode_ring_kernel(DecodeArgs a) {
         int nt = ct + tstride;  // tile whose fragments are requested once this item's run out
         if (nt >= tiles) nt = tile0;  // past the end: harmless re-request of a valid address, never consumed
         typename BFrag<NBW>::type bq[4];
+        pr.item_begin();
 #pragma unroll
         for (int f = 0; f < F; f++) {
             const int g = f / 3, cc = f % 3;
-            if constexpr (!(FR_PROBE_DECODE & 8)) ring_wait<R>(ring[f % R]);
+            if constexpr (!(PR::bits & 8)) ring_wait<R>(ring[f % R]);
+            else asm volatile("" : "+v"(ring[f % R]));
             if (f < 3 * G) {
                 if (cc == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if ((FR_PROBE_DECODE & 16) == 0 || (ct == tile0 && g == 0)) bq[j] = ldb<NBW>(Pll + (size_t)g * 256 * NBW, sw, j);
+                        if ((PR::bits & 16) == 0 || (ct == tile0 && g == 0)) bq[j] = ldb<NBW>(Pll + (size_t)g * 256 * NBW, sw, j);
                     if (g == GS) {  // S finished: park it, restart the fmaf chain from +0 for E
 #pragma unroll
                         for (int c2 = 0; c2 < 3; c2++)
@@ -395,8 +416,8 @@ void decode_ring_kernel(DecodeArgs a) {
                     }
                 }
                 const f32x4 af = ring[f % R];
-                if constexpr (FR_PROBE_DECODE & 1) {
-                    c[cc][0] += af;
+                if constexpr (PR::bits & 1) {
+                    asm volatile("" ::"v"(af), "v"(bq[0]), "v"(bq[3]));  // keeps the fragment and the LDS reads live
                 } else {
                     // k-steps that hold only padding (199 = 12*16 + 7 leaves two of the last shape group's four) are
                     // skipped: their products are +0 (zero basis x zero parameter) and the chains, started from +0, are
@@ -413,13 +434,15 @@ void decode_ring_kernel(DecodeArgs a) {
                 for (int nb = 0; nb < NBW; nb++) c[cc][nb] = (m + sv[cc][nb]) + c[cc][nb];
             }
             // re-request the slot: fragment f + R of this item, or of the next one
-            if constexpr (!(FR_PROBE_DECODE & 8)) {
+            if constexpr (!(PR::bits & 8)) {
                 if (f + R < F) FR_REQ(f % R, f + R, ct)
                 else FR_REQ(f % R, f + R - F, nt)
             }
         }
-        if ((FR_PROBE_DECODE & 32) == 0 || c[0][0][0] + c[1][0][1] + c[2][NBW - 1][2] == 12345.678f)
+        pr.item_mfma_done();
+        if ((PR::bits & 32) == 0 || c[0][0][0] + c[1][0][1] + c[2][NBW - 1][2] == 12345.678f)
             decode_store<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
+        pr.item_end();
 #pragma unroll
         for (int cc = 0; cc < 3; cc++)
 #pragma unroll
@@ -427,39 +450,19 @@ void decode_ring_kernel(DecodeArgs a) {
     }
 #pragma unroll
     for (int f = 0; f < R; f++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[f]));
+    pr.finish((int)blockIdx.x, wave, 1);
 #undef FR_REQ
 }
 
 }  // namespace fr
 
-// The packed buffer holds two images of the basis: the f32 A-fragment image of this file, then (256-byte aligned) the
-// Q30 digit image of fr_decode_q.hip.
-static size_t packed_f32_bytes(int N, int n_shape, int n_exp) {
+// The packed buffer holds the f32 A-fragment image of this file (the Q30 digit image of fr_decode_q.hip is a separate,
+// opt-in buffer: fr_decode_q30_*).
+size_t fr_packed_basis_bytes(int N, int n_shape, int n_exp) {
     using namespace fr;
     size_t tiles = (size_t)tiles_of(N);
     size_t G = (size_t)groups_of(n_shape) + groups_of(n_exp);
     return tiles * G * 3 * 64 * sizeof(float4) + tiles * 3 * TILE_V * sizeof(float);
-}
-static size_t packed_q_offset(int N, int n_shape, int n_exp) {
-    return (packed_f32_bytes(N, n_shape, n_exp) + 255) & ~(size_t)255;
-}
-size_t fr_packed_basis_bytes(int N, int n_shape, int n_exp) {
-    return packed_q_offset(N, n_shape, n_exp) + (fr_decode_q_supported(n_shape, n_exp) ? fr_packed_q_bytes(N, n_shape, n_exp) : 0);
-}
-
-// Arithmetic of the basis blend: FR_DECODE_ARITH_F32 (default: the k-ordered fmaf chain) or FR_DECODE_ARITH_Q30.
-static int g_decode_arith = -1;
-int fr_decode_arith_get() {
-    if (g_decode_arith < 0) {
-        const char* e = getenv("FR_DECODE_ARITH");
-        g_decode_arith = (e && !strcmp(e, "q30")) ? FR_DECODE_ARITH_Q30 : FR_DECODE_ARITH_F32;
-    }
-    return g_decode_arith;
-}
-int fr_decode_arith_set(int mode) {
-    if (mode != FR_DECODE_ARITH_Q30 && mode != FR_DECODE_ARITH_F32) return FR_ERR_INVALID_ARG;
-    g_decode_arith = mode;
-    return FR_OK;
 }
 
 int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
@@ -472,13 +475,10 @@ int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc
     float* mu_p = reinterpret_cast<float*>(A + tiles * G * 3 * 64);
     hipLaunchKernelGGL(pack_basis_kernel, dim3(2048), dim3(256), 0, stream, mu, pc_shape, pc_exp, N, n_shape, n_exp, A,
                        mu_p);
-    if (hipGetLastError() != hipSuccess) return FR_ERR_LAUNCH;
-    if (!fr_decode_q_supported(n_shape, n_exp)) return FR_OK;
-    return fr_launch_pack_q(mu, pc_shape, pc_exp, N, n_shape, n_exp,
-                            reinterpret_cast<char*>(packed) + packed_q_offset(N, n_shape, n_exp), stream);
+    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
-static int device_cu_count() {
+int fr_device_cu_count() {
     static int cus[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
@@ -517,9 +517,6 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
                      int n_exp, float im_size, float* vertex_proj, hipStream_t stream) {
     using namespace fr;
     if (B == 0 || N == 0) return FR_OK;
-    if (fr_decode_arith_get() == FR_DECODE_ARITH_Q30 && fr_decode_q_supported(n_shape, n_exp))
-        return fr_launch_decode_q(params, reinterpret_cast<const char*>(packed) + packed_q_offset(N, n_shape, n_exp),
-                                  R_override, B, N, n_shape, n_exp, im_size, vertex_proj, device_cu_count(), stream);
     size_t tiles = (size_t)tiles_of(N);
     size_t G = (size_t)groups_of(n_shape) + groups_of(n_exp);
     size_t lds = G * KGROUP * 16 * sizeof(float4) + 64 * 12 * sizeof(float) + 64 * 3 * 2 * sizeof(double);
@@ -532,9 +529,11 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
     a.out = vertex_proj;
     a.B = B; a.N = N; a.ns = n_shape; a.ne = n_exp;
     a.im_size = im_size;
-    const int cus = device_cu_count();
-    static const bool loop_env = getenv("FR_DECODE_IMPL") && !strcmp(getenv("FR_DECODE_IMPL"), "loop");
-    static const bool wide_off = getenv("FR_DECODE_WIDE") && !strcmp(getenv("FR_DECODE_WIDE"), "0");
+    const int cus = fr_device_cu_count();
+    const bool loop_env = opt(OPT_DECODE_IMPL) == 1;
+    const bool wide_off = opt(OPT_DECODE_WIDE) == 0;
+    const int nbw_env = opt(OPT_DECODE_NBW), waves_env = opt(OPT_DECODE_WAVES);
+    const bool nt_off = opt(OPT_DECODE_NT) == 0;
     const bool ring_shape = !loop_env && groups_of(n_shape) == 13 && groups_of(n_exp) == 2;
     // 128 columns per pass (64-column items on 12 waves) when more than 64 remain: the basis is streamed once per 128
     // faces instead of once per 64 (102 vs 110 us at B = 128; FR_DECODE_WIDE=0 turns it off)
@@ -549,7 +548,6 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
             continue;
         }
         const int nbt = (min(B - b0, MAXB) + 15) / 16;  // 16-column blocks in this pass (1..4)
-        const int nbw_env = getenv("FR_DECODE_NBW") ? atoi(getenv("FR_DECODE_NBW")) : 0;  // A/B knob, read per call
         int nbw = nbt == 1 ? 1 : 2;                     // column blocks per work item
         if (nbw_env == 4 && nbt > 2) nbw = 4;
         if (nbw_env == 1) nbw = 1;                      // quarter-tile items: 13,304 at B = 64 (12.99 per SIMD)
@@ -557,10 +555,9 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
         // the model's own basis shape (199 + 29 coefficients = 13 + 2 groups) takes the fully unrolled ring schedule
         const bool ring = ring_shape && nbw <= 2;
         int rc;
-        const int waves_env = getenv("FR_DECODE_WAVES") ? atoi(getenv("FR_DECODE_WAVES")) : 16;  // read per call (probe / PipelinedPlan knob)
         if (ring && nbw == 1) rc = launch_decode_ring<13, 2, 8, 1, 16, 64, 4, true>(a, lds, cus, tiles, stream);
         else if (ring && waves_env == 8) rc = launch_decode_ring<13, 2, 8, 2, 8, 64, 4>(a, lds, cus, tiles, stream);
-        else if (ring && getenv("FR_DECODE_NT") && !atoi(getenv("FR_DECODE_NT")))
+        else if (ring && nt_off)
             rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);  // A/B knob: default-policy basis loads
         else if (ring)
             // the basis stream carries the non-temporal hint: it is read once per launch, and keeping its 153 MB out of

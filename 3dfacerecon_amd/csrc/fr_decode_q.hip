@@ -22,8 +22,6 @@
 //   their end read the bytes that follow (harmless: the matching parameter digits are zero), and the 256 bytes that
 //   follow the very first fragment of a tile are its payload: per row {mu_x, mu_y, mu_z, -re_x | -re_y << 10 | -re_z << 20}.
 //   With KB % 4 != 0 the payload therefore arrives in lanes 48..63 of the tile's first fragment load, free of charge.
-#include <mutex>
-
 #include "fr_decode_shared.h"
 
 namespace fr {
@@ -178,6 +176,7 @@ struct DecodeQArgs {
     const int* ce;         // column exponents [S*64]
     QShape qs;
     const char* stage;     // this pass's staged parameters (q_stage_kernel)
+    int cb0;               // generic kernel: first 16-column block of this launch (0, or 2 for the second half of a pass)
 };
 
 constexpr int Q_BE_BAD = 0x7FFFFFFF;
@@ -323,7 +322,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_q_kernel(DecodeQArgs a)
     const int tiles = tiles_of(a.d.N);
     int be[NBW];
 #pragma unroll
-    for (int nb = 0; nb < NBW; nb++) be[nb] = be_s[16 * nb + (lane & 15)];
+    for (int nb = 0; nb < NBW; nb++) be[nb] = be_s[16 * (a.cb0 + nb) + (lane & 15)];
     for (int tile = (int)blockIdx.x * DEC_WAVES + wave; tile < tiles; tile += (int)gridDim.x * DEC_WAVES) {
         const char* tb = a.tiles + (size_t)tile * qs.tile_bytes;
         uint4 pay[4];
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_q_kernel(DecodeQArgs a)
                     i32x4 bf[NBW];
 #pragma unroll
                     for (int nb = 0; nb < NBW; nb++)
-                        bf[nb] = *reinterpret_cast<const i32x4*>(Bimg + ((size_t)((s * 4 + j) * 4 + nb) * 64 + lane) * 16);
+                        bf[nb] = *reinterpret_cast<const i32x4*>(Bimg + ((size_t)((s * 4 + j) * 4 + a.cb0 + nb) * 64 + lane) * 16);
 #pragma unroll
                     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_q_kernel(DecodeQArgs a)
             }
             q_finish<NBW>(acc, mu4, e4, be, v[c]);
         }
-        decode_store<NBW>(a.d, v[0], v[1], v[2], Mt, tile, 0, lane, nbatch, a.d.N);
+        decode_store<NBW>(a.d, v[0], v[1], v[2], Mt, tile, a.cb0 / NBW, lane, nbatch, a.d.N);
     }
 }
 
@@ -524,30 +523,10 @@ size_t fr_packed_q_bytes(int N, int n_shape, int n_exp) {
     return qs.hdr_bytes + (size_t)tiles_of(N) * qs.tile_bytes + 1024;   // + slack: the last short fragment's over-read
 }
 
-// Per-(device, stream) staging buffer of the decode (68 KiB for the model's shape), allocated on first use and kept:
-// launches on one stream are ordered, so its passes can share one buffer; different streams must not.
-static char* q_stage_scratch(hipStream_t stream, size_t bytes) {
-    struct Ent { int dev; hipStream_t stream; char* p; size_t cap; };
-    static Ent tab[64];
-    static int used = 0;
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    for (int i = 0; i < used; i++)
-        if (tab[i].dev == dev && tab[i].stream == stream) {
-            if (tab[i].cap >= bytes) return tab[i].p;
-            char* np = nullptr;   // (a larger basis shape on the same stream: the old buffer may still be in use -- keep it)
-            if (hipMalloc(&np, bytes) != hipSuccess) return nullptr;
-            tab[i].p = np;
-            tab[i].cap = bytes;
-            return np;
-        }
-    if (used == 64) return nullptr;
-    char* np = nullptr;
-    if (hipMalloc(&np, bytes) != hipSuccess) return nullptr;
-    tab[used++] = Ent{dev, stream, np, bytes};
-    return np;
+// Staging buffer of the decode (68 KiB for the model's shape): caller-owned, one per stream in flight -- launches on one
+// stream are ordered, so its passes can share one buffer; different streams must not.
+size_t fr_decode_q_workspace_bytes_impl(int n_shape, int n_exp) {
+    return fr_decode_q_supported(n_shape, n_exp) ? fr::q_stage_bytes(fr::q_shape(n_shape, n_exp).S) : 0;
 }
 
 int fr_launch_pack_q(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
@@ -597,7 +576,7 @@ static int launch_q_ring(const fr::DecodeQArgs& a, int cus, hipStream_t stream) 
 }
 
 int fr_launch_decode_q(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
-                       int n_exp, float im_size, float* vertex_proj, int cus, hipStream_t stream) {
+                       int n_exp, float im_size, float* vertex_proj, void* workspace, size_t ws_bytes, hipStream_t stream) {
     using namespace fr;
     if (B == 0 || N == 0) return FR_OK;
     DecodeQArgs a;
@@ -614,14 +593,16 @@ int fr_launch_decode_q(const float* params, const void* qimage, const float* R_o
     a.d.im_size = im_size;
     const size_t lds = q_stage_bytes(a.qs.S);
     if (lds > 160 * 1024) return FR_ERR_UNSUPPORTED;
-    char* stage = q_stage_scratch(stream, lds);
-    if (!stage) return FR_ERR_LAUNCH;
+    if (!workspace || ws_bytes < lds || ((uintptr_t)workspace & 15)) return FR_ERR_WORKSPACE;
+    char* stage = reinterpret_cast<char*>(workspace);
     a.stage = stage;
+    a.cb0 = 0;
+    const int cus = fr_device_cu_count();
+    const bool loop_env = opt(OPT_DECODE_IMPL) == 1;
     for (int b0 = 0; b0 < B; b0 += MAXB) {
         a.d.b0 = b0;
         hipLaunchKernelGGL(q_stage_kernel, dim3(MAXB), dim3(128), 0, stream, a, stage);
         const int nbt = (min(B - b0, MAXB) + 15) / 16;
-        static const bool loop_env = getenv("FR_DECODE_IMPL") && !strcmp(getenv("FR_DECODE_IMPL"), "loop");
         if (!loop_env && a.qs.KB == QR_KB) {   // the model's basis shape: streaming schedule
             int rc = nbt == 1 ? launch_q_ring<16, 1, 8, true>(a, cus, stream)
                      : nbt == 2 ? launch_q_ring<16, 2, 8, true>(a, cus, stream)
@@ -629,9 +610,13 @@ int fr_launch_decode_q(const float* params, const void* qimage, const float* R_o
             if (rc != FR_OK) return rc;
             continue;
         }
-        int rc = nbt == 1 ? launch_q_generic<1>(a, lds, cus, stream)
-                 : nbt == 2 ? launch_q_generic<2>(a, lds, cus, stream)
-                            : launch_q_generic<4>(a, lds, cus, stream);
+        // (three or four column blocks: two passes of two -- one wave holding four blocks' 112 accumulators spills)
+        int rc = nbt == 1 ? launch_q_generic<1>(a, lds, cus, stream) : launch_q_generic<2>(a, lds, cus, stream);
+        if (rc == FR_OK && nbt > 2) {
+            a.cb0 = 2;
+            rc = launch_q_generic<2>(a, lds, cus, stream);
+            a.cb0 = 0;
+        }
         if (rc != FR_OK) return rc;
     }
     return FR_OK;

@@ -431,9 +431,15 @@ __device__ __forceinline__ bool id_ok(float f, int n, int& p) {
 // fr_render_pack_tri) instead of once per (face, triangle) -- phase A of the emit kernel then costs one 16-byte load per
 // triangle.  Entry = {4*p1, 4*p2, 4*p3, valid}; an invalid triangle (an id outside [0,nver): deviation 3, the reference
 // would read out of bounds) carries offsets 0 (safe dummy gathers) and valid = 0.
+// The slot behind the table's capacity holds a header {magic, nver, ntri, 0}: the emit kernel treats every triangle as
+// invalid (the planes come out as pure background) when the table it is handed was not packed for its (nver, ntri) --
+// a caller of the phase-by-phase entry point that skipped the pack phase, or reused the workspace for another shape,
+// gets a defined result instead of out-of-bounds gathers.
+constexpr int TRI4_MAGIC = 0x46525434;  // "FRT4"
 __global__ __launch_bounds__(256) void pack_tri_kernel(const float* __restrict__ tri, int nver, int ntri,
-                                                       int4* __restrict__ out) {
+                                                       int4* __restrict__ out, int4* __restrict__ hdr) {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) *hdr = make_int4(TRI4_MAGIC, nver, ntri, 0);
     if (t >= ntri) return;
     int p1, p2, p3;
     const bool ok = id_ok(tri[t], nver, p1) & id_ok(tri[(size_t)ntri + t], nver, p2) &
@@ -491,6 +497,8 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
 
     // ---------------- phase A: pre-validated ids, gathers, bbox reject ----------------
     {
+        const int4 hdr = a.tri4[(size_t)a.nseg * SEG];  // uniform: which (nver, ntri) the table was packed for
+        const int table_ok = (int)(hdr.x == TRI4_MAGIC) & (int)(hdr.y == nver) & (int)(hdr.z == ntri);
         bool surv[TPT], single[TPT];
         int4 e[TPT];
         float x1[TPT], x2[TPT], x3[TPT], y1[TPT], y2[TPT], y3[TPT], z1[TPT], z2[TPT], z3[TPT];
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             // one unconditional 16-byte load (saddr + 32-bit offset form); no short-circuit on .w, or the compiler
             // splits the load and serialises the two halves
             e[u] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.tri4) + (size_t)((uint32_t)min(t, ntri - 1) << 4));
-            valid[u] = ((int)(tid < EMIT_ACTIVE) & (int)(t < ntri) & e[u].w) != 0;
+            valid[u] = ((int)(tid < EMIT_ACTIVE) & (int)(t < ntri) & e[u].w & table_ok) != 0;
         }
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
@@ -995,6 +1003,7 @@ struct BwdRenderArgs {
     float* vertex_grad;       // [B,3,nver]
     int nver, ntri, npix;     // npix = H*W
     int splits, range;        // owner workgroups per face, vertices per owner
+    int shift;                // headroom bits given up by images above 2^20 pixels: ceil(log2 npix) - 20, else 0
 };
 
 // the three vertex ids of pixel value `tv` (a float-stored triangle index, -1 on the background): false when the pixel
@@ -1084,7 +1093,7 @@ __global__ __launch_bounds__(256) void bwd_records_kernel(BwdRenderArgs a, int4*
             const bool ok = t[u] >= 0 && (unsigned)p1 < (unsigned)a.nver && (unsigned)p2 < (unsigned)a.nver &&
                             (unsigned)p3 < (unsigned)a.nver;
             out[i] = make_int4(ok ? p1 : -1, p2, p3, (int)__float_as_uint(gq[u]));
-            if (ok) {  // the face's largest |g| over the contributing pixels, in parts (max is order independent)
+            if (t[u] >= 0) {  // the face's largest |g| over the covered pixels (the predicate of bwd_face_max), in parts
                 const uint32_t v = __float_as_uint(gq[u]) & 0x7FFFFFFFu;
                 if (v >= 0x7F800000u) bad = 1; else m = max(m, v);
             }
@@ -1168,8 +1177,8 @@ __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArg
     // scale 2^k from e = floor(log2 max|g|): the largest term c = g/3 lands in [2^38, 2^40); up to 2^21 terms (3 per
     // pixel) stay below 2^62
     const int e = (int)(m >> 23) - 127;  // floor(log2 max|g|) for a normal float; -127 for subnormals / zero
-    const double scale = ldexp(1.0, 40 - e);
-    const double inv_scale = ldexp(1.0, e - 40);
+    const double scale = ldexp(1.0, 40 - a.shift - e);
+    const double inv_scale = ldexp(1.0, e - 40 + a.shift);
     float* facc = reinterpret_cast<float*>(acc);  // Inf / NaN gradients: fp32 LDS atomics in the same buffer
     if (bad) {
         __syncthreads();
@@ -1257,15 +1266,6 @@ __global__ __launch_bounds__(BWD_BLOCK) void render_backward_kernel(BwdRenderArg
 
 }  // namespace fr
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-static bool env_is(const char* name, const char* val) {
-    const char* v = getenv(name);
-    return v && strcmp(v, val) == 0;
-}
-
 namespace {
 struct RenderGeom {
     int rows, strips, nseg;
@@ -1295,7 +1295,7 @@ RenderGeom render_geom(int B, int ntri, int H, int W, int rows_override) {
     g.recs_bytes = (size_t)B * g.nseg * fr::SEG * sizeof(uint4);
     g.segoff_bytes = (size_t)B * g.nseg * fr::OFF_STRIDE * sizeof(uint16_t);
     g.nrm_bytes = (size_t)B * g.nseg * fr::SEG * sizeof(float4);  // per-record normals; also bounds the tritex table
-    g.tri4_bytes = (size_t)g.nseg * fr::SEG * sizeof(int4);       // pre-validated triangle table
+    g.tri4_bytes = ((size_t)g.nseg * fr::SEG + 1) * sizeof(int4);  // pre-validated triangle table + its header slot
     // An 8x4 hit window may touch at most TWO strips (its own bucket or the boundary bucket between them): with strips
     // shorter than the window (a very wide image, or the override) it could span three and the emit kernel's bucket
     // choice would drop hits -- such shapes take the scan path instead.
@@ -1304,7 +1304,7 @@ RenderGeom render_geom(int B, int ntri, int H, int W, int rows_override) {
                   (long long)B * g.nseg <= 0x7FFFFFFFll;
     return g;
 }
-RenderGeom render_geom(int B, int ntri, int H, int W) { return render_geom(B, ntri, H, W, env_int("FR_RENDER_ROWS", 0)); }
+RenderGeom render_geom(int B, int ntri, int H, int W) { return render_geom(B, ntri, H, W, fr::opt(fr::OPT_RENDER_ROWS)); }
 }  // namespace
 
 // test hook (tests/test_render_gpu.py): div3(x) against x / 3.0f on the bit patterns [first, first + count)
@@ -1405,11 +1405,11 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     a.im_gray = im_gray; a.net_in = net_in; a.depth_img = depth_img;
     a.wm1 = (float)(W - 1);
     a.hm1 = (float)(H - 1);
-    a.resolve_opt = env_int("FR_RESOLVE_OPT", 1);
-    a.use_filter = env_int("FR_EMIT_FILTER", 3);   // bit 0: certified fp32 inside test, bit 1: single-pixel pre-cull in phase A
+    a.resolve_opt = opt(OPT_RESOLVE_OPT);
+    a.use_filter = opt(OPT_EMIT_FILTER);  // bit 0: certified fp32 inside test, bit 1: single-pixel pre-cull in phase A
     a.rows_magic = g.rows > 1 ? (uint32_t)((0x100000000ull + (unsigned)g.rows - 1) / (unsigned)g.rows) : 0u;
 
-    const bool binned = g.binned_ok && ntri > 0 && !env_is("FR_RENDER_IMPL", "scan");
+    const bool binned = g.binned_ok && ntri > 0 && opt(OPT_RENDER_IMPL) != 1;
     if (fused && !binned) return FR_ERR_UNSUPPORTED;  // the caller falls back to the unfused op + elementwise post-processing
     a.tri4 = nullptr; a.nseg_magic = 0;
     if (!binned) {
@@ -1434,12 +1434,13 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     a.nseg_magic = ((unsigned long long)B * g.nseg * g.nseg < 0x100000000ull && g.nseg > 1)
                        ? (uint32_t)((0x100000000ull + (unsigned)g.nseg - 1) / (unsigned)g.nseg) : 0u;
     if (phases & 4)
-        hipLaunchKernelGGL(pack_tri_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, tri, nver, ntri, tri4);
+        hipLaunchKernelGGL(pack_tri_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, tri, nver, ntri, tri4,
+                           tri4 + (size_t)g.nseg * SEG);
     if (phases & 1)
         hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
     if (!(phases & 2)) return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
     // 256-thread resolvers when several of them fit a CU's LDS side by side, 512 threads for wide strips
-    const int rblk = env_int("FR_RESOLVE_BLOCK", g.lds <= 32 * 1024 ? 256 : 512);
+    const int rblk = opt(OPT_RESOLVE_BLOCK) > 0 ? opt(OPT_RESOLVE_BLOCK) : (g.lds <= 32 * 1024 ? 256 : 512);
     int rc;
     if (rblk == 1024)
         rc = fused ? launch_resolve<1024, true>(a, nbins, g.lds, stream) : launch_resolve<1024, false>(a, nbins, g.lds, stream);
@@ -1466,7 +1467,11 @@ int fr_launch_render_backward(const float* depth_grad, const float* tri, const f
     const long long npix = (long long)H * W;
     if (npix * B == 0 || ntri == 0 || nver == 0)
         return (!bytes || hipMemsetAsync(vertex_grad, 0, bytes, stream) == hipSuccess) ? FR_OK : FR_ERR_LAUNCH;
-    if (npix > (1ll << 20)) return FR_ERR_UNSUPPORTED;  // the int64 headroom covers 3 * 2^20 terms per vertex
+    if (npix > 0x7FFFFFFFll) return FR_ERR_UNSUPPORTED;
+    // the int64 headroom covers 3 * 2^20 terms per vertex at the full 38-bit resolution; larger images give up one bit of
+    // resolution per doubling (the forward renders them through the scan fallback, so the backward must take them too)
+    int shift = 0;
+    while ((1ll << (20 + shift)) < npix) shift++;
     // owners per face: enough for the LDS budget, and for ~one workgroup per CU on small batches
     int splits = (nver + BWD_RANGE_MAX - 1) / BWD_RANGE_MAX;
     const int want = (256 + B - 1) / B;
@@ -1477,7 +1482,7 @@ int fr_launch_render_backward(const float* depth_grad, const float* tri, const f
     if ((long long)B * splits > 0x7FFFFFFFll) return FR_ERR_UNSUPPORTED;
     BwdRenderArgs a;
     a.depth_grad = depth_grad; a.tri = tri; a.tri_ind = tri_ind; a.vertex_grad = vertex_grad;
-    a.nver = nver; a.ntri = ntri; a.npix = (int)npix; a.splits = splits; a.range = range;
+    a.nver = nver; a.ntri = ntri; a.npix = (int)npix; a.splits = splits; a.range = range; a.shift = shift;
     // with a workspace one pre-kernel resolves every pixel to its vertex ids once (instead of once per owner workgroup)
     // and the owners stream 16-byte records
     const bool packed = workspace && ws_bytes >= fr_render_backward_workspace_bytes_impl(B, H, W) &&

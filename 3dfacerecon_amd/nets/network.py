@@ -39,22 +39,75 @@ def _ops():
     return _load("_fr_hotpath_ops", os.path.join("rendering_layer", "ops.py"))
 
 
+class PackedBasis:
+    """The constant basis (a tf.constant of the reference model, network.py:41-43) in the layouts the decode kernels
+    stream: the f32 MFMA-fragment image, built at once (fr_decode_pack_basis), and -- only if the opt-in Q30 arithmetic
+    is ever selected (_lib.set_decode_arith / FR_DECODE_ARITH=q30) -- its digit image, built on first use.  A default user
+    holds 153 MB per basis and never launches a q_* kernel."""
+
+    def __init__(self, mu, pc_shape, pc_exp, nvert, ndim_shape, ndim_exp, device):
+        h = _host()
+        L = h.lib()
+        self.mu, self.pc_shape, self.pc_exp = mu, pc_shape, pc_exp
+        self.nvert, self.ndim_shape, self.ndim_exp, self.device = nvert, ndim_shape, ndim_exp, device
+        nbytes = L.fr_decode_packed_basis_bytes(nvert, ndim_shape, ndim_exp)
+        self.image = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            rc = L.fr_decode_pack_basis(h.ptr(mu), h.ptr(pc_shape), h.ptr(pc_exp), nvert, ndim_shape, ndim_exp,
+                                        h.ptr(self.image), nbytes, h.stream_ptr(device))
+        h.check(rc, "fr_decode_pack_basis")
+        self._qimage = None
+        self.q30_ws_bytes = L.fr_decode_q30_workspace_bytes(ndim_shape, ndim_exp)
+
+    def use_q30(self):
+        """True when the Q30 entry point serves this call: selected AND the shape is covered (else the f32 chain)."""
+        h = _host()
+        return h.decode_arith() == h.DECODE_ARITH_Q30 and self.q30_ws_bytes > 0
+
+    def qimage(self):
+        if self._qimage is None:
+            h = _host()
+            L = h.lib()
+            nbytes = L.fr_decode_q30_image_bytes(self.nvert, self.ndim_shape, self.ndim_exp)
+            buf = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = L.fr_decode_q30_pack(h.ptr(self.mu), h.ptr(self.pc_shape), h.ptr(self.pc_exp), self.nvert,
+                                          self.ndim_shape, self.ndim_exp, h.ptr(buf), nbytes, h.stream_ptr(self.device))
+            h.check(rc, "fr_decode_q30_pack")
+            self._qimage = buf
+        return self._qimage
+
+    def decode(self, params, R, B, im_size, out, workspace=None):
+        """One decode launch on torch's current stream.  `workspace` (Q30 only): a caller-owned staging buffer of
+        q30_ws_bytes; by default one is taken from torch's caching allocator for this call (stream-safe)."""
+        h = _host()
+        L = h.lib()
+        dev = params.device
+        with torch.cuda.device(dev):
+            if self.use_q30():
+                ws = workspace if workspace is not None else torch.empty((self.q30_ws_bytes,), dtype=torch.uint8, device=dev)
+                rc = L.fr_decode_3dmm_q30(h.ptr(params), h.ptr(self.qimage()), h.ptr(R), B, self.nvert, self.ndim_shape,
+                                          self.ndim_exp, float(im_size), h.ptr(out), h.ptr(ws), self.q30_ws_bytes,
+                                          h.stream_ptr(dev))
+                h.check(rc, "fr_decode_3dmm_q30")
+            else:
+                rc = L.fr_decode_3dmm(h.ptr(params), h.ptr(self.image), h.ptr(R), B, self.nvert, self.ndim_shape,
+                                      self.ndim_exp, float(im_size), h.ptr(out), h.stream_ptr(dev))
+                h.check(rc, "fr_decode_3dmm")
+
+
 class _Decode3DMM(torch.autograd.Function):
     """vertices_transform as one autograd node: fr_decode_3dmm forward, fr_decode_3dmm_backward for the gradient TF
     autodiff derives from network.py:140-171 (d alpha, d beta, d t3d, d f; the three angles get zero because the
     reference's rotation goes through tf.py_func, network.py:150, which has no gradient)."""
 
     @staticmethod
-    def forward(ctx, params, net, R, packed=None, im_size=None):
-        h = _host()
+    def forward(ctx, params, net, R, basis=None, im_size=None):
         B = int(params.shape[0])
         out = torch.empty((B, 3, net.nvert), dtype=torch.float32, device=params.device)
-        packed = net._packed if packed is None else packed
+        basis = net._basis if basis is None else basis
         im_size = float(net.im_size if im_size is None else im_size)
-        with torch.cuda.device(params.device):
-            rc = h.lib().fr_decode_3dmm(h.ptr(params), h.ptr(packed), h.ptr(R), B, net.nvert, net.ndim_shape,
-                                        net.ndim_exp, im_size, h.ptr(out), h.stream_ptr(params.device))
-        h.check(rc, "fr_decode_3dmm")
+        basis.decode(params, R, B, im_size, out)
         ctx.net = net
         ctx.im_size = im_size
         ctx.save_for_backward(params, out, R if R is not None else params.new_empty(0))
@@ -125,16 +178,9 @@ class FaceRecNet:
             raise ValueError("pc_shape / pc_exp must be (3*Nvert, ndim)")
 
         # one-time re-layout of the constant basis into MFMA-fragment order (include/fr_hotpath.h)
-        h = _host()
-        L = h.lib()
-        nbytes = L.fr_decode_packed_basis_bytes(self.nvert, self.ndim_shape, self.ndim_exp)
-        self._packed = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=self.device)
-        with torch.cuda.device(self.device):
-            rc = L.fr_decode_pack_basis(h.ptr(self.mu), h.ptr(self.pc_shape), h.ptr(self.pc_exp), self.nvert,
-                                        self.ndim_shape, self.ndim_exp, h.ptr(self._packed), nbytes,
-                                        h.stream_ptr(self.device))
-        h.check(rc, "fr_decode_pack_basis")
-        self._packed_nomu = None  # second image with mu = 0, built on first use by geometry_product()
+        self._basis = PackedBasis(self.mu, self.pc_shape, self.pc_exp, self.nvert, self.ndim_shape, self.ndim_exp,
+                                  self.device)
+        self._basis_nomu = None  # second image with mu = 0, built on first use by geometry_product()
 
         # initial parameters (network.py:57-62)
         geo = torch.zeros((batch_size, self.ndim_shape + self.ndim_exp), **f32)
@@ -170,24 +216,17 @@ class FaceRecNet:
         im_size = 1).  The y row comes out as (1 - y) - 1, i.e. -y to within half an ulp of max(1, |y|) -- the loss
         squares it.  Differentiable (fr_decode_3dmm_backward)."""
         h = _host()
-        L = h.lib()
         g = h.require_gpu_f32(geometry_params, "geometry_params")
         B = int(g.shape[0])
         if g.dim() != 2 or g.shape[1] != self.ndim_shape + self.ndim_exp:
             raise ValueError("geometry_params must be (B,%d)" % (self.ndim_shape + self.ndim_exp))
-        if self._packed_nomu is None:
-            nbytes = L.fr_decode_packed_basis_bytes(self.nvert, self.ndim_shape, self.ndim_exp)
-            buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=self.device)
-            with torch.cuda.device(self.device):
-                rc = L.fr_decode_pack_basis(h.ptr(torch.zeros_like(self.mu)), h.ptr(self.pc_shape), h.ptr(self.pc_exp),
-                                            self.nvert, self.ndim_shape, self.ndim_exp, h.ptr(buf), nbytes,
-                                            h.stream_ptr(self.device))
-            h.check(rc, "fr_decode_pack_basis")
-            self._packed_nomu = buf
+        if self._basis_nomu is None:
+            self._basis_nomu = PackedBasis(torch.zeros_like(self.mu), self.pc_shape, self.pc_exp, self.nvert,
+                                           self.ndim_shape, self.ndim_exp, self.device)
         pose = torch.zeros((B, self.ndim_pose), dtype=torch.float32, device=g.device)
         pose[:, 6] = 1.0
         eye = torch.eye(3, dtype=torch.float32, device=g.device)[None].repeat(B, 1, 1).contiguous()
-        return _Decode3DMM.apply(torch.cat([pose, g], 1), self, eye, self._packed_nomu, 1.0)
+        return _Decode3DMM.apply(torch.cat([pose, g], 1), self, eye, self._basis_nomu, 1.0)
 
     # ---- rendering layer wrapper --------------------------------------------------------------------------
     def rendering_layer(self, vertex_proj, triangles, colors, im_gray=None):

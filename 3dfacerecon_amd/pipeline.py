@@ -59,8 +59,20 @@ class DecodeRenderPlan:
         self._ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=self.device)
         self._ws_bytes = ws_bytes
         p = h.ptr
-        self._dec_args = (p(self.params), p(net._packed), None, self.B, self.N, net.ndim_shape, net.ndim_exp,
-                          ctypes.c_float(float(net.im_size)), p(self.vertex_proj))
+        # the decode entry point is fixed when the plan is built: the f32 chain, or -- when the opt-in Q30 arithmetic is
+        # selected at that moment -- fr_decode_3dmm_q30 with a staging workspace the PLAN owns (nothing is allocated at
+        # launch time, so the plan can be captured on any stream)
+        basis = net._basis
+        self.q30 = basis.use_q30()
+        if self.q30:
+            self._q_ws = torch.empty((basis.q30_ws_bytes,), dtype=torch.uint8, device=self.device)
+            self._dec_fn = self._L.fr_decode_3dmm_q30
+            self._dec_args = (p(self.params), p(basis.qimage()), None, self.B, self.N, net.ndim_shape, net.ndim_exp,
+                              ctypes.c_float(float(net.im_size)), p(self.vertex_proj), p(self._q_ws), basis.q30_ws_bytes)
+        else:
+            self._dec_fn = self._L.fr_decode_3dmm
+            self._dec_args = (p(self.params), p(basis.image), None, self.B, self.N, net.ndim_shape, net.ndim_exp,
+                              ctypes.c_float(float(net.im_size)), p(self.vertex_proj))
         self._ren_args = (p(self.vertex_proj), p(net.tri), p(self.texture), self.B, self.N, self.T, self.H, self.W, 3,
                           self.tex_batch, p(self.depth), p(self.texture_image), p(self.normal), p(self.tri_ind),
                           p(self._ws), ws_bytes)
@@ -83,9 +95,9 @@ class DecodeRenderPlan:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def decode(self):
-        rc = self._L.fr_decode_3dmm(*self._dec_args, self._stream())
+        rc = self._dec_fn(*self._dec_args, self._stream())
         if rc:
-            self._h.check(rc, "fr_decode_3dmm")
+            self._h.check(rc, "fr_decode_3dmm_q30" if self.q30 else "fr_decode_3dmm")
 
     def render(self):
         rc = self._L.fr_render_depth_forward_phases(*self._ren_args, self._stream(), 3)

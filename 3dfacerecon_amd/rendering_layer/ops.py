@@ -13,9 +13,11 @@ C ABI of include/fr_hotpath.h through ctypes on torch's current HIP stream.  Lik
 module loads the native library and builds it first if the .so is missing (reference ops.py:63-72) -- but there
 is no fallback path: no library or no GPU tensor => an exception.
 """
+import collections
 import importlib.util
 import os
 import sys
+import threading
 
 import torch
 
@@ -54,16 +56,57 @@ _host().lib()
 # (device, stream), grown on demand.  The forward writes every part it later reads and nothing of it is needed by the
 # backward, so calls on one stream can share it; the reference cudaMallocs / cudaFrees six buffers per call
 # (render_depth_op.cu.cc:272-277, 335-340).
-_WS_CACHE = {}
+#   * bounded: at most WS_CACHE_MAX entries, least recently used evicted first (a caller that cycles streams no longer
+#     accumulates one 330 MB buffer per stream handle it ever used); clear_workspace_cache() drops them all;
+#   * never used while the current stream is being captured into a hipGraph: a captured launch must not point at a buffer
+#     the cache may later replace, so the capture gets a buffer of its own from the graph's memory pool;
+#   * guarded by a lock (autograd worker threads call the forward too).
+# Each entry also remembers which triangle list its pre-validated triangle table (pack_tri_kernel) was built from --
+# (data_ptr, torch version counter, geometry) -- so a loop that renders with the same `tri` tensor every call (the
+# reference makes it a tf.constant, network.py:178) packs it once, not once per call.  The version counter sees in-place
+# torch writes; a caller that rewrites the tensor's memory behind torch's back must call clear_workspace_cache().
+WS_CACHE_MAX = 4
+_WS_CACHE = collections.OrderedDict()
+_WS_LOCK = threading.Lock()
+
+
+class _WsEntry:
+    __slots__ = ("buf", "tri_key")
+
+    def __init__(self, buf):
+        self.buf = buf
+        self.tri_key = None
+
+
+def clear_workspace_cache():
+    """Releases every cached render workspace (their memory returns to torch's caching allocator)."""
+    with _WS_LOCK:
+        _WS_CACHE.clear()
 
 
 def _workspace(dev, nbytes):
+    """-> (entry, cached): the workspace entry for torch's current stream on `dev`."""
+    if torch.cuda.is_current_stream_capturing():
+        return _WsEntry(torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)), False
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
-    ws = _WS_CACHE.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
-        _WS_CACHE[key] = ws
-    return ws
+    with _WS_LOCK:
+        ent = _WS_CACHE.get(key)
+        if ent is None or ent.buf.numel() < nbytes:
+            ent = _WsEntry(torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev))
+            _WS_CACHE[key] = ent
+        _WS_CACHE.move_to_end(key)
+        while len(_WS_CACHE) > WS_CACHE_MAX:
+            _WS_CACHE.popitem(last=False)
+    return ent, True
+
+
+def _render_phases(ent, cached, tri_c, geom):
+    """7 (pack + emit + resolve) or 3 when the entry's triangle table was packed from this very list for this geometry."""
+    key = (tri_c.data_ptr(), tri_c._version) + geom
+    if cached and ent.tri_key == key:
+        return 3
+    ent.tri_key = key if cached else None
+    return 7
 
 
 def _check_forward_shapes(ver, tri, texture, image):
@@ -121,10 +164,16 @@ class _RenderDepth(torch.autograd.Function):
         L = h.lib()
         with torch.cuda.device(dev):
             ws_bytes = L.fr_render_depth_workspace_bytes(B, nver, ntri, H, W)
-            ws = _workspace(dev, ws_bytes) if ws_bytes else None
-            rc = L.fr_render_depth_forward(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), B, nver, ntri, H, W, 3, tex_batch,
-                                           h.ptr(depth), h.ptr(tex_img), h.ptr(normal), h.ptr(tri_ind), h.ptr(ws),
-                                           ws_bytes, h.stream_ptr(dev))
+            if ws_bytes:
+                ent, cached = _workspace(dev, ws_bytes)
+                phases = _render_phases(ent, cached, tri_c, (B, nver, ntri, H, W))
+                rc = L.fr_render_depth_forward_phases(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), B, nver, ntri, H, W, 3,
+                                                      tex_batch, h.ptr(depth), h.ptr(tex_img), h.ptr(normal), h.ptr(tri_ind),
+                                                      h.ptr(ent.buf), ws_bytes, h.stream_ptr(dev), phases)
+            else:
+                rc = L.fr_render_depth_forward(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), B, nver, ntri, H, W, 3, tex_batch,
+                                               h.ptr(depth), h.ptr(tex_img), h.ptr(normal), h.ptr(tri_ind), None, 0,
+                                               h.stream_ptr(dev))
         h.check(rc, "fr_render_depth_forward")
         ctx.save_for_backward(tri_c, tri_ind)
         ctx.dims = (B, nver, ntri, H, W)
@@ -174,10 +223,11 @@ class _RenderingLayerFused(torch.autograd.Function):
         L = h.lib()
         with torch.cuda.device(dev):
             ws_bytes = L.fr_render_depth_workspace_bytes(B, nver, ntri, H, W)
-            ws = _workspace(dev, ws_bytes)
+            ent, _ = _workspace(dev, ws_bytes)
+            ent.tri_key = None   # (this entry point always repacks the triangle table)
             rc = L.fr_rendering_layer_forward(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), h.ptr(img_c), B, nver, ntri, H, W,
                                               tex_batch, h.ptr(net_in), h.ptr(depth_img), h.ptr(depth), h.ptr(tri_ind),
-                                              h.ptr(ws), ws_bytes, h.stream_ptr(dev))
+                                              h.ptr(ent.buf), ws_bytes, h.stream_ptr(dev))
         if rc == -4:
             raise NotImplementedError("fused rendering layer: shape only covered by the fallback rasteriser")
         h.check(rc, "fr_rendering_layer_forward")

@@ -1,14 +1,18 @@
-"""Image / label batch generators with the reference's contract (utils/data_process.py:7-101): the host-side feeders of
-the CoarseNet -> render loop (`im_gray` [B,H,W,1] float64 minus the dataset mean, `params_label` [B,1,1,235]).
+"""Host-side feeders of the CoarseNet -> render loop: image / label batches with the reference's contract
+(utils/data_process.py:7-101) -- `im_gray` [B,H,W,1] float64 minus the dataset mean, `params_label` [B,1,1,235].
 
-The reference decodes with cv2.imread (BGR, always 3 channels); OpenCV is not in this image, so files are decoded with
-Pillow into the same BGR uint8 array (`read_image_bgr`; `.npy` arrays are accepted too, for tests and for callers that
-already hold decoded frames).  Behaviour kept from the reference, on purpose:
-  * gray = 0.3 R + 0.59 G + 0.11 B in float64, minus `img_mean` (data_process.py:30-31); the image must already have the
-    network's size -- 3-channel images are NOT resized (only 2-D arrays are, and those skip the mean subtraction, :26-28);
-  * a missing file raises FileNotFoundError, an undecodable one IOError, a label of the wrong length IOError (:17-35, :49-59);
-  * the generators walk the list with `counter = (counter + batch_size) % len(files)` (:83, :100): when the list length
-    is not a multiple of the batch size the short tail slice fails the `len == batch_size` assertion, as there.
+Design: two pure per-sample decoders (`load_gray`, `load_label`), one batch assembler (`_stack`) and ONE cursor class
+(`ListCursor`) that walks a list file in batch-sized windows; the reference's public names (`prepare_input_image`,
+`prepare_input_label`, `trainval_generator`, `test_generator`) are thin views of those.  OpenCV is not in this image, so
+files are decoded with Pillow into the BGR uint8 array cv2.imread would return (`read_image_bgr`; `.npy` arrays are
+accepted too, for tests and for callers that already hold decoded frames).
+
+Behaviour that is the reference's and is held by tests/test_assets_cpu.py (as behaviour, not as copied code):
+  * gray = 0.3 R + 0.59 G + 0.11 B in float64, minus `img_mean` (reference :30-31); a 3-channel image must already have
+    the network's size -- only 2-D arrays are resized, and those skip the mean subtraction (:26-28);
+  * a missing file raises FileNotFoundError, an undecodable one IOError, a label of the wrong length IOError;
+  * the window start advances by the batch size modulo the list length (:83, :100), so a list whose length is not a
+    multiple of the batch size eventually yields a short window, which fails the `len == batch_size` assertion.
 """
 import os
 
@@ -20,6 +24,7 @@ except ImportError:  # pragma: no cover
     import listfile_reader as file_reader
 
 ROOT_PATH = os.path.join(os.path.dirname(__file__), '..', '..')
+GRAY_WEIGHTS_BGR = np.array([0.11, 0.59, 0.3])  # B, G, R
 
 
 def read_image_bgr(path):
@@ -28,83 +33,110 @@ def read_image_bgr(path):
         return np.load(path)
     from PIL import Image
     with Image.open(path) as im:
-        rgb = np.asarray(im.convert('RGB'), np.uint8)
-    return rgb[:, :, ::-1]
+        return np.asarray(im.convert('RGB'), np.uint8)[:, :, ::-1]
 
 
 def _resize_nearest(im, size_wh):
     w, h = int(size_wh[0]), int(size_wh[1])  # cv2.resize takes (width, height)
-    ys = np.minimum((np.arange(h) + 0.5) * im.shape[0] / h, im.shape[0] - 1).astype(int)
-    xs = np.minimum((np.arange(w) + 0.5) * im.shape[1] / w, im.shape[1] - 1).astype(int)
-    return im[ys][:, xs]
+    rows = np.minimum((np.arange(h) + 0.5) * im.shape[0] / h, im.shape[0] - 1).astype(int)
+    cols = np.minimum((np.arange(w) + 0.5) * im.shape[1] / w, im.shape[1] - 1).astype(int)
+    return im[np.ix_(rows, cols)]
+
+
+def _existing(path):
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    return path
+
+
+def load_gray(path, img_size, img_mean):
+    """One image file -> [h, w] float64 network input plane."""
+    try:
+        im = read_image_bgr(_existing(path))
+    except FileNotFoundError:
+        raise
+    except Exception:
+        raise IOError(path)
+    if im.ndim == 2:   # already gray: resized, no mean subtraction
+        return _resize_nearest(im, img_size).astype(np.float64)
+    if im.ndim != 3:
+        raise IOError(path)
+    b, g, r = (im[:, :, k] for k in range(3))
+    return (GRAY_WEIGHTS_BGR[2] * r + GRAY_WEIGHTS_BGR[1] * g + GRAY_WEIGHTS_BGR[0] * b) - img_mean
+
+
+def load_label(path, label_dim):
+    """One whitespace-separated label file -> [label_dim] float64."""
+    try:
+        vec = np.loadtxt(_existing(path))
+    except FileNotFoundError:
+        raise
+    except Exception:
+        raise IOError(path)
+    if vec.shape != (label_dim,):
+        raise IOError(path)
+    return vec
+
+
+def _stack(files, batch_size, sample_shape, load):
+    assert len(files) == batch_size
+    out = np.zeros((batch_size,) + tuple(sample_shape))
+    for row, path in zip(out, files):
+        row[...] = np.reshape(load(path), sample_shape)
+    return out
 
 
 def prepare_input_image(image_files, batch_size, img_size, img_mean=127.0):
-    ''' a batch of image files -> [batchsize, h, w, 1] float64 (reference data_process.py:7-35) '''
-    assert len(image_files) == batch_size
-    input_image = np.zeros([batch_size, img_size[0], img_size[1], 1])
-    for i in range(batch_size):
-        if not os.path.exists(image_files[i]):
-            raise FileNotFoundError(image_files[i])
-        try:
-            im = read_image_bgr(image_files[i])
-        except Exception:
-            raise IOError(image_files[i])
-        if im.ndim == 2:      # gray image already: resized, stored as it is (no mean subtraction, as in the reference)
-            input_image[i, :, :, 0] = _resize_nearest(im, img_size)
-        elif im.ndim == 3:
-            # R: 0.3, G: 0.59, B: 0.11 on a BGR array
-            im_gray = 0.3 * im[:, :, 2] + 0.59 * im[:, :, 1] + 0.11 * im[:, :, 0]
-            input_image[i, :, :, 0] = im_gray - img_mean
-        else:
-            raise IOError(image_files[i])
-    return input_image
+    """A batch of image files -> [batchsize, h, w, 1] float64."""
+    return _stack(image_files, batch_size, (img_size[0], img_size[1], 1), lambda p: load_gray(p, img_size, img_mean))
 
 
 def prepare_input_label(label_files, batch_size, label_dim):
-    '''a batch of label files -> [batchsize, 1, 1, label_dim] float64 (reference data_process.py:39-60)'''
-    assert len(label_files) == batch_size
-    input_label = np.zeros([batch_size, 1, 1, label_dim])
-    for i in range(batch_size):
-        if not os.path.exists(label_files[i]):
-            raise FileNotFoundError(label_files[i])
-        try:
-            labels = np.loadtxt(label_files[i])
-        except Exception:
-            raise IOError(label_files[i])
-        if labels.ndim == 1 and labels.shape[0] == label_dim:
-            input_label[i, 0, 0, :] = labels
-        else:
-            raise IOError(label_files[i])
-    return input_label
+    """A batch of label files -> [batchsize, 1, 1, label_dim] float64."""
+    return _stack(label_files, batch_size, (1, 1, label_dim), lambda p: load_label(p, label_dim))
+
+
+class ListCursor:
+    """Endless iterator over batch-sized windows of one or more parallel file lists; `make_batch(*windows)` turns the
+    windows into what the caller wants.  The start of the window moves by `batch_size` modulo the list length."""
+
+    def __init__(self, lists, batch_size, make_batch):
+        self.lists = [list(l) for l in lists]
+        self.batch_size = int(batch_size)
+        self.make_batch = make_batch
+        self.start = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        lo, hi = self.start, self.start + self.batch_size
+        batch = self.make_batch(*[l[lo:hi] for l in self.lists])
+        self.start = hi % len(self.lists[0])
+        return batch
+
+
+_TRAINVAL_LISTS = {'train': 'train_list.txt', 'val': 'val_list.txt'}
 
 
 def trainval_generator(batch_size, img_size, label_dim, dataset=None, img_mean=127.0, phase='train'):
-    '''Endless generator of (images, labels) batches from <ROOT>/data/<dataset> (an absolute `dataset` path is used as
-    it is); phase 'train' reads train_list.txt, 'val' val_list.txt (reference data_process.py:63-83).'''
-    dataset_path = os.path.join(ROOT_PATH, 'data', dataset)
-    if phase == 'train':
-        image_files, label_files = file_reader.read_listfile_trainval(dataset_path, 'train_list.txt')
-    elif phase == 'val':
-        image_files, label_files = file_reader.read_listfile_trainval(dataset_path, 'val_list.txt')
-    else:
-        raise NotImplementedError
-    counter = 0
-    while True:
-        yield prepare_input_image(image_files[counter:counter + batch_size], batch_size, img_size, img_mean), \
-            prepare_input_label(label_files[counter:counter + batch_size], batch_size, label_dim)
-        counter = (counter + batch_size) % len(image_files)
+    """Endless (images, labels) batches from <ROOT>/data/<dataset> (an absolute `dataset` is used as it is): phase
+    'train' reads train_list.txt, 'val' val_list.txt; any other phase raises NotImplementedError at the first batch."""
+    def gen():
+        if phase not in _TRAINVAL_LISTS:
+            raise NotImplementedError(phase)
+        images, labels = file_reader.read_listfile_trainval(os.path.join(ROOT_PATH, 'data', dataset),
+                                                            _TRAINVAL_LISTS[phase])
+        yield from ListCursor([images, labels], batch_size,
+                               lambda im, lab: (prepare_input_image(im, batch_size, img_size, img_mean),
+                                                prepare_input_label(lab, batch_size, label_dim)))
+    return gen()
 
 
 def test_generator(batch_size, img_size, dataset=None, img_mean=127.0):
-    '''Endless generator of (images, image file names) batches from test_list.txt (reference data_process.py:86-101).'''
-    dataset_path = os.path.join(ROOT_PATH, 'data', dataset)
-    image_files = file_reader.read_listfile_test(dataset_path, 'test_list.txt')
-    counter = 0
-    while True:
-        yield prepare_input_image(image_files[counter:counter + batch_size], batch_size, img_size, img_mean), \
-            image_files[counter:counter + batch_size]
-        counter = (counter + batch_size) % len(image_files)
+    """Endless (images, image file names) batches from test_list.txt."""
+    images = file_reader.read_listfile_test(os.path.join(ROOT_PATH, 'data', dataset), 'test_list.txt')
+    return ListCursor([images], batch_size, lambda im: (prepare_input_image(im, batch_size, img_size, img_mean), im))
 
 
 test_generator.__test__ = False  # not a pytest test

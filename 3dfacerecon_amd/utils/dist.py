@@ -63,6 +63,37 @@ def sum_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def gather_over_ranks(value, device="cpu"):
+    """The python float of every rank, in rank order (the bench's per-rank step times)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
+def describe(device="cpu"):
+    """What the process group itself reports -- so that a bench line can prove what RCCL saw: backend, the world size as
+    dist.get_world_size() returns it, and how many ranks answered a SUM all-reduce of ones."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": 1, "ranks_reporting": 1}
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+            "ranks_reporting": int(round(sum_over_ranks(1.0, device)))}
+
+
+def bench_partition(batch, rank, world, scaling="weak"):
+    """Faces of one bench step owned by `rank`: -> (first_face, local_batch, global_batch).
+    weak: every rank runs its own `batch` faces (global = world * batch); strong: ONE `batch`-face job is cut into
+    contiguous shards with shard_range (8 faces per GPU for 64 faces on 8 GPUs), global = batch."""
+    if scaling == "weak":
+        return rank * int(batch), int(batch), world * int(batch)
+    if scaling == "strong":
+        lo, hi = shard_range(batch, rank, world)
+        return lo, hi - lo, int(batch)
+    raise ValueError("scaling must be 'weak' or 'strong'")
+
+
 def finalize():
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

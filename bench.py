@@ -124,6 +124,14 @@ def cpu_baseline(assets, params_np, n_faces, H, W, synth):
                   "(network.py:140-171 as two fp32 matmuls) + fr_oracle_render_depth_forward (render_depth_op.cc:132-322 "
                   "restated), one thread pinned to one core, %.1f s" % (n_faces, chunk - 1, total),
         "value_uses": "decode_blas_ms_per_face + render_op_ms_per_face",
+        "value_is": "the WHOLE timed path on one CPU thread (decode + the op's CPU functor, render_depth_op.cc:132-322) -- the "
+                    "like-for-like baseline of `value`.  north_star's 'reference CPU z-buffer (prepare_data/ZBuffer)' is the "
+                    "RENDER-ONLY figure north_star_reference_cpu_zbuffer below (it has no decode stage); both speed-ups are "
+                    "reported in speedup_vs_cpu",
+        "north_star_reference_cpu_zbuffer": {
+            "faces_per_s": 1.0 / zb, "ms_per_face": 1e3 * zb, "faces_timed": nz, "cores": 1,
+            "what": "MM3D::ZBuffer + PointInTri (prepare_data/ZBuffer/ModalAndRef.cpp:3-142) restated in oracle/fr_oracle.c, "
+                    "all-double column-major as the MEX computes, render only (no 3DMM decode), one face per call"},
         "decode_blas_ms_per_face": 1e3 * t_dec / n_faces,
         "render_op_ms_per_face": 1e3 * t_ren / n_faces,
         "render_only_faces_per_s": {"op_cpu_functor": n_faces / t_ren, "zbuffer_mex": 1.0 / zb},
@@ -131,6 +139,80 @@ def cpu_baseline(assets, params_np, n_faces, H, W, synth):
         "decode_spec_oracle_ms_per_face": 1e3 * (ts1 - ts0) / ns,
         "host_cpu_model": host_cpu_model(), "host_cpus": os.cpu_count(),
     }
+
+
+def parity_gate(plan, net, assets, params_np, H, W, n_faces):
+    """The timed route's own buffers against the CPU oracle, on the first `n_faces` faces of this rank's batch.
+      * render: oracle rasteriser (render_depth_op.cc:132-322 restated) on the PLAN'S vertex_proj -> all four planes
+        bit for bit (a NaN equals a NaN);
+      * decode with the host rotation (what the reference's tf.py_func hands over, network.py:150) through the same
+        kernel: bit for bit against the spec oracle (nets/network.py:140-171);
+      * the plan's decode itself evaluates the rotation in-kernel in float64 (device sincos vs glibc: last-bit
+        differences in fp64 that survive the fp32 rounding only rarely): held to <= 2 ulp and >= 99 % equal, the bar
+        tests/test_decode_gpu.py states."""
+    import numpy as np
+    import torch
+    from oracle import oracle as O
+    n = min(int(n_faces), plan.B)
+    plan.step()
+    torch.cuda.synchronize(plan.device)
+    V = plan.vertex_proj[:n].cpu().numpy()
+    got = [t[:n].cpu().numpy() for t in plan.outputs()]
+    want = O.render_depth(V, assets["tri"], assets["vertex"][None], H, W)
+    bad_planes = 0
+    for g, w in zip(got, want):
+        for b in range(n):
+            if not np.array_equal(g[b], w[b], equal_nan=True):
+                bad_planes += 1
+    R = O.rotation_matrix_batch(params_np[:n, :3])
+    Vo = O.decode_3dmm(params_np[:n], assets["mu"], assets["pc_shape"], assets["pc_exp"], float(H), R=R)
+    Vr = net.vertices_transform(plan.params[:n], R=torch.as_tensor(R, device=plan.device))
+    torch.cuda.synchronize(plan.device)
+    bad_decode = int(sum(not np.array_equal(Vr[b].cpu().numpy(), Vo[b]) for b in range(n)))
+    # in-kernel rotation leg: distance in units in the last place of the oracle's value
+    a = V.view(np.int32).astype(np.int64)
+    o = Vo.view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    o = np.where(o < 0, -(o & 0x7FFFFFFF), o)
+    ulp = np.abs(a - o)
+    frac_equal = float((ulp == 0).mean())
+    max_ulp = int(ulp.max())
+    ok = bad_planes == 0 and bad_decode == 0 and max_ulp <= 2 and frac_equal >= 0.99
+    return {"faces": n, "route": "DecodeRenderPlan (fr_decode_3dmm + fr_render_depth_forward_phases(3))",
+            "mismatching_planes": bad_planes, "planes_checked": 4 * n,
+            "decode_host_rotation_mismatching_faces": bad_decode,
+            "decode_inkernel_rotation": {"max_ulp": max_ulp, "frac_bit_equal": frac_equal, "bar": "<= 2 ulp, >= 0.99 equal"},
+            "ok": bool(ok)}
+
+
+def ops_surface_leg(net, ops, plan, B, H, W, K, Wm, R, dist_u, dev):
+    """K steps of the reference's own call chain (nets/network.py:153-182): net.vertices_transform(params) ->
+    rendering_layer.ops.render_depth(ver, tri, texture, image), output allocation per call included (as
+    render_depth_op.cc:442-445 allocates per call).  Same brackets as the plan's timed region; median of R blocks."""
+    import torch
+    image = torch.zeros((B, H, W, 3), dtype=torch.float32, device=dev)
+    params = plan.params
+
+    def one():
+        ver = net.vertices_transform(params)
+        return ops.render_depth(ver, net.tri, net.vertex_code, image)
+
+    with torch.no_grad():
+        for _ in range(Wm):
+            outs = one()
+        blocks = []
+        for _ in range(R):
+            dist_u.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(K):
+                outs = one()
+            torch.cuda.synchronize(dev)
+            blocks.append(dist_u.max_over_ranks(time.perf_counter() - t0, device=dev))
+            dist_u.barrier()
+    same = all(torch.equal(a, b) for a, b in zip(outs, plan.outputs()))
+    blocks.sort()
+    return blocks[(len(blocks) - 1) // 2], same
 
 
 def main():
@@ -143,6 +225,12 @@ def main():
     ap.add_argument("--repeats", type=int, default=10, help="timed K-step blocks; the median block is reported")
     ap.add_argument("--cpu-faces", type=int, default=2048, help="faces in the cpu_baseline sample (0 = skip); 2048 ~ 10 s")
     ap.add_argument("--graph", action="store_true", help="also report hipGraph-replay throughput")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch faces per GPU; strong: ONE --batch-face job cut into per-rank shards")
+    ap.add_argument("--parity-faces", type=int, default=-1,
+                    help="faces per rank the oracle checks before the line is printed (-1 = all of them; 0 = skip, the "
+                         "line then carries parity = null and must not be quoted)")
+    ap.add_argument("--no-ops-surface", action="store_true", help="skip the operator-surface leg")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,10 +249,16 @@ def main():
     synth = pkg("utils.synth")
     netm = pkg("nets.network")
     pipe = pkg("pipeline")
-    B, H, W = args.batch, args.im_size, args.im_size
+    H, W = args.im_size, args.im_size
+    first, B, B_global = dist_u.bench_partition(args.batch, rank, world, args.scaling)
+    if B == 0:
+        raise SystemExit("bench.py --scaling strong: %d faces cannot be cut into %d non-empty shards" % (args.batch, world))
     assets = synth.make_assets()
     net = netm.FaceRecNet(mesh_data=assets, batch_size=B, im_size=H, device=dev)
-    params_np = synth.sample_params_batch(B, im_size=H, beta=0.7, seed=3456 + rank)
+    if args.scaling == "strong":   # every rank draws the ONE global batch and keeps its own shard
+        params_np = synth.sample_params_batch(args.batch, im_size=H, beta=0.7, seed=3456)[first:first + B]
+    else:
+        params_np = synth.sample_params_batch(B, im_size=H, beta=0.7, seed=3456 + rank)
     plan = pipe.DecodeRenderPlan(net, B, H, W)
     plan.params.copy_(torch.as_tensor(params_np, device=dev))
     torch.cuda.synchronize(dev)
@@ -209,6 +303,28 @@ def main():
     blocks = [dist_u.max_over_ranks(t, device=dev) for t in local]
     order = sorted(range(R), key=lambda i: blocks[i])
     elapsed = blocks[order[(R - 1) // 2]]          # the median block (lower median for an even R)
+    per_rank_ms = [1e3 * t / K for t in dist_u.gather_over_ranks(local[order[(R - 1) // 2]], device=dev)]
+    dist_info = dist_u.describe(device=dev)
+    faces_per_step = int(round(dist_u.sum_over_ranks(B, device=dev)))   # what the ranks actually ran, counted by the group
+
+    # the operator-surface route (allocations + pack_tri every call): same K / W / R, reported beside `value`
+    ops_elapsed = ops_same = None
+    if not args.no_ops_surface:
+        ops_elapsed, ops_same = ops_surface_leg(net, pkg("rendering_layer.ops"), plan, B, H, W, K, Wm, R, dist_u, dev)
+
+    # parity gate: the oracle on every face of the timed route's buffers, on every rank
+    parity = None
+    if args.parity_faces != 0:
+        parity = parity_gate(plan, net, assets, params_np, H, W, B if args.parity_faces < 0 else args.parity_faces)
+        all_ok = dist_u.sum_over_ranks(0.0 if parity["ok"] else 1.0, device=dev) == 0.0
+        parity["faces_all_ranks"] = int(round(dist_u.sum_over_ranks(parity["faces"], device=dev)))
+        parity["mismatching_planes_all_ranks"] = int(round(dist_u.sum_over_ranks(parity["mismatching_planes"], device=dev)))
+        if not all_ok:
+            if rank == 0 or not parity["ok"]:
+                print("bench.py: PARITY GATE FAILED on rank %d: %s" % (rank, json.dumps(parity)), file=sys.stderr)
+            dist_u.barrier()
+            dist_u.finalize()
+            sys.exit(3)
     decode_ms = sum(e[0].elapsed_time(e[1]) for e in ev_all) / len(ev_all)
     emit_ms = sum(e[1].elapsed_time(e[2]) for e in ev_all) / len(ev_all)
     resolve_ms = sum(e[2].elapsed_time(e[3]) for e in ev_all) / len(ev_all)
@@ -229,13 +345,14 @@ def main():
     if rank == 0:
         N, T, Kc = net.nvert, int(net.tri.shape[1]), net.ndim_shape + net.ndim_exp
         ab = algorithmic_bytes(N, T, Kc, H, W, B)
-        value = world * B * K / elapsed
+        assert faces_per_step == B_global, (faces_per_step, B_global)
+        value = faces_per_step * K / elapsed
         flops = 2.0 * 3 * N * Kc * B
         # algorithmic bytes of the render op (1,948,403 B/face) split over its two kernels: the emit kernel
         # owns the vertex / triangle / texture reads, the resolve kernel the four output planes
         emit_bytes = (4.0 * 3 * N + (4.0 * 3 * T + 4.0 * 3 * N) / B) * B
         resolve_bytes = 4.0 * H * W * 8 * B
-        q30 = pkg("_lib").lib().fr_decode_get_arith() == 0   # FR_DECODE_ARITH=q30 (opt-in; the default is the f32 chain)
+        q30 = plan.q30   # FR_DECODE_ARITH=q30 (opt-in, frozen experiment; the default is the f32 chain)
         if q30:   # int8-MFMA blend: the matrix pipe is no longer the bound, the 153 MB basis + 41 MB output stream is
             roof_decode = {"bound": "hbm", "kernel": "q_stage_kernel + decode_q_ring_kernel<16,4,8> (fr_decode_3dmm, Q30)",
                            "achieved": ab["decode"] * B / (decode_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -277,16 +394,19 @@ def main():
         out = {
             "metric": "faces/sec (3DMM decode+depth render), batch 64 @200x200",
             "value": value, "unit": "faces/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": args.scaling,
             "repeats": R, "value_is": "median over %d timed blocks of K steps each" % R,
-            "value_min": world * B * K / max(blocks), "value_max": world * B * K / min(blocks),
+            "value_min": faces_per_step * K / max(blocks), "value_max": faces_per_step * K / min(blocks),
             "ms_per_step_min": 1e3 * min(blocks) / K, "ms_per_step_max": 1e3 * max(blocks) / K,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: batch %d random 235-d params -> 3DMM decode -> depth render, "
-                                   "%dx%d, fp32, all four output planes" % (B, H, W),
-                       "faces_per_gpu": B, "nver": N, "ntri": T, "n_shape": net.ndim_shape, "n_exp": net.ndim_exp,
-                       "sampler": "sample_test.py:23-38 beta=0.7 seed=3456+rank", "coverage": cov,
-                       "sharding": "batch over ranks, no data-path collective",
+                                   "%dx%d, fp32, all four output planes" % (args.batch, H, W),
+                       "faces_per_gpu": B if args.scaling == "weak" else None, "faces_per_step_all_gpus": faces_per_step,
+                       "faces_per_gpu_rank0": B, "nver": N, "ntri": T, "n_shape": net.ndim_shape, "n_exp": net.ndim_exp,
+                       "sampler": "sample_test.py:23-38 beta=0.7 " + ("seed=3456+rank" if args.scaling == "weak" else "seed=3456, one batch for all ranks"), "coverage": cov,
+                       "sharding": ("weak: every rank runs its own %d faces" % B if args.scaling == "weak" else
+                                    "strong: ONE %d-face batch cut into contiguous shards (utils.dist.shard_range)" % args.batch)
+                                   + ", no data-path collective",
                        "decode_arith": "q30 (exact fixed point on the int8 MFMA)" if q30 else "f32 fmaf chain (f32-input MFMA)",
                        "constants": "the packed basis (fr_decode_pack_basis) and the pre-validated triangle table "
                                     "(fr_render_depth_forward_phases, phase 4) are built once per plan: both are "
@@ -298,11 +418,25 @@ def main():
                              "achieved_GBs": ab["pipeline"] * value / world / 1e9,
                              "frac_of_8TBs": ab["pipeline"] * value / world / 1e9 / HBM_PEAK_GBS,
                              "frac_of_measured_copy_6.29TBs": ab["pipeline"] * value / world / 1e9 / HBM_COPY_GBS},
+            "parity": parity,
+            "dist": dict(dist_info, per_rank_ms_per_step=per_rank_ms, launcher_world_size=world),
         }
+        if ops_elapsed is not None:
+            out["ops_surface_faces_per_s"] = faces_per_step * K / ops_elapsed
+            out["ops_surface"] = {"ms_per_step": 1e3 * ops_elapsed / K, "vs_plan": elapsed / ops_elapsed,
+                                  "outputs_identical_to_plan": bool(ops_same),
+                                  "route": "FaceRecNet.vertices_transform -> rendering_layer.ops.render_depth (outputs "
+                                           "allocated per call; the pre-validated triangle table is reused while the "
+                                           "same `tri` tensor is passed: ops._render_phases)"}
         if graph_fps is not None:
             out["graph_replay_faces_per_s"] = graph_fps
         if args.cpu_faces > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(assets, params_np, args.cpu_faces, H, W, synth)
+            cb = cpu_baseline(assets, params_np, args.cpu_faces, H, W, synth)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu"] = {
+                "vs_cpu_baseline_value (decode + op functor, 1 thread)": value / cb["value"],
+                "vs_north_star_reference_cpu_zbuffer (render only, 1 thread; the GPU figure includes the decode)":
+                    value / cb["north_star_reference_cpu_zbuffer"]["faces_per_s"]}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -4,7 +4,10 @@ rendering layer, FineNet, forward only or the reference's training step, one pro
 network gradients through torch DDP).  Shaped like the reference's train loop (trainval.py:79-125: train step, then a
 full forward on a validation batch every iteration) with synthetic images / labels.
 
-    python examples/coarse_loop.py --batch 32 --steps 5                       # config 3: CoarseNet + render forward, 1 GPU
+    python examples/coarse_loop.py --config 3      # presets: 3 = CoarseNet + render forward, batch 32, 1 GPU;
+                                                   #          4 = train loop, 256 faces over the ranks (32 per GPU at N = 8);
+                                                   #          5 = Coarse + Fine joint forward at 448 x 448, 128 faces over the ranks
+    python examples/coarse_loop.py --batch 32 --steps 5                       # config 3 spelled out
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29501 \
         examples/coarse_loop.py --batch 32 --steps 5 --train                  # config 4: 256 faces over 8 GPUs
     ... --im-size 448 --batch 16 --fine                                       # config 5: Coarse + Fine joint forward
@@ -78,8 +81,31 @@ def build_harness(args, dev, rank, world, local):
     return model, net, opt, step
 
 
+# BASELINE.json configs[2..4] as presets; the global batch is cut over the ranks that are present (one process per GPU)
+CONFIG_PRESETS = {
+    3: dict(label="configs[2]: CoarseNet (ResNet-101) + render_depth end-to-end forward, batch 32, 1 GPU",
+            global_batch=32, im_size=200, train=False, val=False, fine=False),
+    4: dict(label="configs[3]: CoarseNet train loop, batch 256 sharded over the ranks, RCCL all-reduce",
+            global_batch=256, im_size=200, train=True, val=True, fine=True),
+    5: dict(label="configs[4]: CoarseNet + FineNet joint forward, 448x448 input, batch 128 over the ranks",
+            global_batch=128, im_size=448, train=False, val=False, fine=True),
+}
+
+
+def ddp_bucket_bytes(model, net):
+    """Gradient bytes one training step all-reduces: every parameter that requires grad, fp32, once per step (DDP's
+    buckets partition exactly this set); 0 when the model is not wrapped (single rank / forward only)."""
+    if net is model:
+        return 0
+    return int(sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, choices=sorted(CONFIG_PRESETS), default=None,
+                    help="BASELINE.json config preset (3, 4 or 5): sets batch / im-size / train / val / fine; on fewer GPUs "
+                         "than the config names each rank runs global_batch / max(world, named GPUs) faces (its shard)")
+    ap.add_argument("--shard-gpus", type=int, default=8, help="GPUs configs 4 and 5 are quoted on (their per-GPU shard)")
     ap.add_argument("--batch", type=int, default=32, help="faces per GPU")
     ap.add_argument("--im-size", type=int, default=200)
     ap.add_argument("--nIter", type=int, default=4)
@@ -93,6 +119,12 @@ def main():
     args = ap.parse_args()
     dist_u = pkg("utils.dist")
     world, rank, local = dist_u.init_from_env()
+    preset = None
+    if args.config is not None:
+        preset = CONFIG_PRESETS[args.config]
+        named = 1 if args.config == 3 else args.shard_gpus
+        args.batch = preset["global_batch"] // max(world, named)
+        args.im_size, args.train, args.val, args.fine = preset["im_size"], preset["train"], preset["val"], preset["fine"]
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     model, net, opt, step = build_harness(args, dev, rank, world, local)
@@ -107,9 +139,16 @@ def main():
         out, L = step()
     torch.cuda.synchronize(dev)
     dt = dist_u.max_over_ranks(time.perf_counter() - t0, device=dev)
+    dist_info = dist_u.describe(device=dev)   # (a collective: every rank calls it)
     if rank == 0:
         name = "configs[4]" if args.fine and not args.train else ("configs[3]" if args.train else "configs[2]")
-        rec = {"config": "%s coarse_loop" % name, "n_gpus": world, "faces_per_gpu": args.batch, "im_size": args.im_size,
+        rec = {"metric": "faces/sec, caller config (%s)" % (preset["label"] if preset else name + " coarse_loop"),
+               "value": world * args.batch * args.steps / dt, "unit": "faces/s", "higher_is_better": True,
+               "data": "synthetic", "dtype": "f32", "scaling": "weak (per-GPU shard fixed)",
+               "config": "%s coarse_loop" % name, "n_gpus": world, "faces_per_gpu": args.batch, "im_size": args.im_size,
+               "global_batch_this_run": world * args.batch,
+               "dist": dist_info,
+               "ddp_allreduce_bytes_per_step": ddp_bucket_bytes(model, net),
                "nIter": args.nIter, "train": args.train, "val_forward": args.val, "fine": args.fine or args.train,
                "steps": args.steps, "faces_per_s": world * args.batch * args.steps / dt,
                "ms_per_step": 1e3 * dt / args.steps,

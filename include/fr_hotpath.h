@@ -7,9 +7,8 @@
  * interface it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds to rendering_layer/ops.py.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer owned by the caller (outputs and workspace included); the library
- *     allocates nothing (one exception: selecting FR_DECODE_ARITH_Q30 makes the library keep a 68 KiB staging buffer per
- *     (device, stream), allocated on first use) and never synchronises with the host;
+ *   - every pointer is a DEVICE pointer owned by the caller (outputs and workspaces included); the library
+ *     allocates nothing and never synchronises with the host;
  *   - `hip_stream` is a hipStream_t (NULL = the default stream); all work is enqueued on it, in order;
  *   - return value: FR_OK (0) or a negative FR_ERR_* code (never swallowed, unlike the reference's
  *     printf-and-return at render_depth_op.cu.cc:290-295); fr_strerror() names it;
@@ -38,6 +37,18 @@ extern "C" {
 const char* fr_version(void);
 const char* fr_strerror(int code);
 
+/* Tuning / A-B knobs of the launchers (no reference counterpart).  Each knob is named like the environment variable
+ * that gives it its initial value -- read ONCE per process, at the first use of any knob; the launch path never calls
+ * getenv -- and can be changed afterwards only through fr_set_option:
+ *   FR_DECODE_IMPL (0 | 1 = "loop": generic decode kernel)   FR_DECODE_WIDE (1 | 0)   FR_DECODE_NBW (0 = auto | 1 | 4)
+ *   FR_DECODE_WAVES (16 | 8)   FR_DECODE_NT (1 | 0: default cache policy for the basis stream)
+ *   FR_RESOLVE_OPT (1 | 0)   FR_EMIT_FILTER (bits 0-1, default 3)   FR_RENDER_IMPL (0 | 1 = "scan": strip-scan fallback)
+ *   FR_RESOLVE_BLOCK (0 = auto | 256 | 512 | 1024)   FR_RENDER_ROWS (0 = auto | rows per screen strip)
+ * None of them changes a result bit (tests/test_render_gpu.py, tests/test_decode_gpu.py hold every setting to the oracle).
+ * Returns FR_OK or FR_ERR_INVALID_ARG (unknown name). */
+int fr_set_option(const char* name, int value);
+int fr_get_option(const char* name, int* value);
+
 /* ---- render_depth forward ------------------------------------------------------------------------------
  * Replaces RenderDepthOp<Device>::Compute + functor RenderDepth (render_depth_op.cc:378-458, 132-322;
  * CUDA launchers render_depth_op.cu.cc:239-341) reached from rendering_layer/ops.py:78-81.
@@ -60,7 +71,10 @@ int fr_render_depth_forward(const float* vertex, const float* tri, const float* 
  * records into the workspace; resolve_write_kernel (bit 2) turns them into the four planes.  phases = 7 is
  * fr_render_depth_forward.  A caller whose triangle list is a constant of the model (the reference makes it a
  * tf.constant, nets/network.py:178) and whose workspace persists may pack once (phases = 4) and then run phases = 3
- * per batch: emit consumes whatever table the workspace holds.  bench.py also uses single phases to bracket each
+ * per batch.  The table carries a header naming the (nver, ntri) it was packed for: an emit phase handed a table that
+ * was not packed for its arguments (no pack phase yet, or the workspace reused for another shape) treats every triangle
+ * as invalid and the planes come out as pure background -- defined, never an out-of-bounds gather.  The table does NOT
+ * record the ids themselves: repack after changing `tri` in place.  bench.py also uses single phases to bracket each
  * kernel with HIP events inside the timed region. */
 int fr_render_depth_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver,
                                    int ntri, int H, int W, int C, int tex_batch, float* depth, float* tex_img,
@@ -86,9 +100,11 @@ int fr_rendering_layer_forward(const float* vertex, const float* tri, const floa
  *   depth_grad [B,H,W,1], tri [3,ntri], tri_ind [B,H,W,1] (forward output) -> vertex_grad [B,3,nver]
  * Every pixel with tri_ind >= 0 adds (depth_grad * 1.0f) / 3.0f to the z row of its triangle's three vertices; the x and
  * y rows are 0 (render_depth_op.cc:359-363); all of vertex_grad is written.  The per-vertex sums are formed as exact
- * 64-bit fixed-point integers and rounded once: the result is the correctly rounded real sum up to n * 2^-39 * max|term|
- * per face and is bit-identical from run to run (the reference's serial loop has one fixed fp32 order; its CUDA twin
- * uses order-dependent float atomics).  Images above 2^20 pixels return FR_ERR_UNSUPPORTED. */
+ * 64-bit fixed-point integers and rounded to fp32 once (a subnormal result is rounded a second time by the final power-of-
+ * two scaling): the result is the correctly rounded real sum up to n * 2^-39 * max|term| per face and is bit-identical
+ * from run to run (the reference's serial loop has one fixed fp32 order; its CUDA twin uses order-dependent float
+ * atomics).  max|term| is taken over the pixels with 0 <= tri_ind < ntri.  Images above 2^20 pixels give up one bit of
+ * that resolution per doubling of the pixel count (2^-38 at 2^21 pixels, ...). */
 int fr_render_depth_backward(const float* depth_grad, const float* tri, const float* tri_ind,
                              float* vertex_grad, int B, int nver, int ntri, int H, int W, void* hip_stream);
 
@@ -122,23 +138,28 @@ int fr_decode_pack_basis(const float* mu, const float* pc_shape, const float* pc
  *               with NULL the rotation is evaluated in-kernel in float64 exactly as network.py:276-290 does.
  *   vertex_proj [B,3,N]; y row is (im_size - y) - 1 (network.py:167-169).
  * Numerical definition: the reference evaluates S = pc_shape.alpha and E = pc_exp.beta with two fp32
- * tf.matmuls whose summation order is unspecified (network.py:153-156).  Two written definitions are offered:
- *   FR_DECODE_ARITH_F32 (default)  S, E = k-ordered fmaf chains from +0, v = (mu + S) + E  (the f32-input MFMA; the
- *       reference's own arithmetic type).
- *   FR_DECODE_ARITH_Q30            v = fl32(mu + S + E) with S + E an EXACT fixed-point dot product of the operands
- *       quantised to 31 bits against power-of-two row / column scales (int8 matrix cores, 16 digit products): the
- *       correctly rounded fp32 value of the real-number blend in > 99 % of the cases (half the f32 chain's mean error);
- *       a non-finite parameter makes the face's vertices NaN.  n_shape + n_exp above 512 falls back to F32.  Measured
- *       2-11 % slower than F32 inside the 64-face pipeline, hence not the default.
- * Both are restated on the CPU in oracle/fr_oracle.c and the kernels are held to them bit for bit.  The choice is a
- * process-wide setting (initial value from the environment variable FR_DECODE_ARITH = "f32" | "q30"). */
-#define FR_DECODE_ARITH_Q30 0
-#define FR_DECODE_ARITH_F32 1
-int fr_decode_set_arith(int mode);   /* FR_OK or FR_ERR_INVALID_ARG */
-int fr_decode_get_arith(void);
-
+ * tf.matmuls whose summation order is unspecified (network.py:153-156).  fr_decode_3dmm's written definition:
+ *   S, E = k-ordered fmaf chains from +0, v = (mu + S) + E  (the f32-input MFMA; the reference's own arithmetic type),
+ * restated on the CPU in oracle/fr_oracle.c; the kernel is held to it bit for bit. */
 int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R_override, int B, int N,
                    int n_shape, int n_exp, float im_size, float* vertex_proj, void* hip_stream);
+
+/* Opt-in second definition of the same decode (frozen experiment; nothing of it is built, allocated or
+ * launched unless these entry points are called):
+ *   Q30: v = fl32(mu + S + E) with S + E an EXACT fixed-point dot product of the operands quantised to 31 bits against
+ *   power-of-two row / column scales (int8 matrix cores, 16 digit products): the correctly rounded fp32 value of the
+ *   real-number blend in > 99 % of the cases (half the f32 chain's mean error); a non-finite parameter makes the face's
+ *   vertices NaN.  Measured 2-11 % slower than fr_decode_3dmm inside the 64-face pipeline, hence not the default.
+ * It has its own basis image (fr_decode_q30_image_bytes, 256-byte aligned; 0 = shape not covered: n_shape + n_exp > 512,
+ * for which fr_decode_q30_pack / fr_decode_3dmm_q30 return FR_ERR_UNSUPPORTED) and needs a caller-owned staging
+ * workspace (fr_decode_q30_workspace_bytes: 68 KiB for the model's shape, 16-byte aligned) that must not be shared by
+ * launches in flight on different streams.  Restated in oracle/fr_oracle.c ("Q30 decode"), held bit for bit. */
+size_t fr_decode_q30_image_bytes(int N, int n_shape, int n_exp);
+int fr_decode_q30_pack(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
+                       void* qimage, size_t qimage_bytes, void* hip_stream);
+size_t fr_decode_q30_workspace_bytes(int n_shape, int n_exp);
+int fr_decode_3dmm_q30(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
+                       int n_exp, float im_size, float* vertex_proj, void* workspace, size_t ws_bytes, void* hip_stream);
 
 /* ---- 3DMM decode backward (the gradient TF autodiff derives from nets/network.py:140-171) ------------
  *   grad_vertex_proj [B,3,N] = dL/d vertex_proj;  vertex_proj [B,3,N] = the forward output (used for d f);

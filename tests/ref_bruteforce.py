@@ -85,3 +85,36 @@ def render_depth_bruteforce(vertex, tri, texture, H, W, pit_batch):
                 normal[b, yy, xx] = nrm
                 tind[b, yy, xx, 0] = F32(i)
     return depth, teximg, normal, tind
+
+
+def render_depth_grad_bruteforce(depth_grad, tri, tri_ind, nver):
+    """TEST-SIDE restatement of RenderDepthGrad(CPUDevice) as a WHOLE function (render_depth_op.cc:344-366): plain Python,
+    pixels in row-major order (b, then j = row, then i = column: :344-346), `depth_grad_ * 1.0f / 3.0f` evaluated in fp32
+    left to right (:361-363) and added with a sequential fp32 `+=` to the z row of the triangle's three vertices, in the
+    order p1, p2, p3.  Shares no code with oracle/fr_oracle.c.  Under the two stated deviations:
+      1. vertex_grad starts from zero (the reference adds into an uninitialised output);
+      2. pixels with tri_ind outside [0, ntri) are skipped (the reference indexes tri(., -1));
+      3. triangles with a vertex id outside [0, nver) are skipped (the reference would write out of bounds).
+    depth_grad [B,H,W,1] f32, tri [3,T] f32, tri_ind [B,H,W,1] f32 -> vertex_grad [B,3,nver] f32."""
+    g = np.ascontiguousarray(depth_grad, F32)
+    tri = np.ascontiguousarray(tri, F32)
+    ti = np.ascontiguousarray(tri_ind, F32)
+    B, H, W = g.shape[:3]
+    ntri = tri.shape[1]
+    out = np.zeros((B, 3, nver), F32)
+    one, three = F32(1.0), F32(3.0)
+    with np.errstate(all="ignore"):
+        for b in range(B):
+            gz = out[b, 2]
+            for j in range(H):
+                for i in range(W):
+                    t = _int_cast(float(ti[b, j, i, 0]))          # int tri_ind_ = tri_ind(b,j,i,0)   (:350)
+                    if t < 0 or t >= ntri:
+                        continue
+                    p = [_int_cast(float(tri[k, t])) for k in range(3)]   # :351-353
+                    if any(q < 0 or q >= nver for q in p):
+                        continue
+                    c = F32(F32(g[b, j, i, 0] * one) / three)     # depth_grad_ * 1.0f / 3.0f, fp32, left to right
+                    for q in p:                                   # :361-363, p1 then p2 then p3
+                        gz[q] = F32(gz[q] + c)
+    return out

@@ -166,3 +166,50 @@ def test_workspace_and_plain_entry_points_agree(oracle, full_assets, synth):
     torch.cuda.synchronize()
     assert torch.equal(got_ws, plain)
     assert float(got_ws[:, 2].abs().max()) > 0
+
+
+def test_backward_of_an_image_above_2_pow_20_pixels(oracle):
+    """the forward renders a 1,100 x 1,000 image (scan fallback: the strip does not fit the binned path's
+    geometry) -- its backward must not refuse it.  Above 2^20 pixels the fixed-point scale gives up one bit per doubling
+    (header): still bit-reproducible, within the stated bound of the float64 sum; both entry points agree."""
+    import ctypes
+    from conftest import pkg
+    h = pkg("_lib")
+    L = h.lib()
+    rs = np.random.RandomState(12)
+    H, W, nver = 1100, 1000, 400
+    assert H * W > (1 << 20)
+    ver = np.empty((1, 3, nver), np.float32)
+    ver[0, 0] = rs.uniform(0, W, nver)
+    ver[0, 1] = rs.uniform(0, H, nver)
+    ver[0, 2] = rs.uniform(-5, 5, nver)
+    tri = rs.randint(0, nver, (3, 300)).astype(np.float32)
+    tex = rs.uniform(0, 1, (1, 3, nver)).astype(np.float32)
+    img = torch.zeros((1, H, W, 3), device="cuda:0")
+    depth, _, _, tind = ops().render_depth(_t(ver), _t(tri), _t(tex), img)
+    want_f = oracle.render_depth(ver, tri, tex, H, W)
+    np.testing.assert_array_equal(tind.cpu().numpy(), want_f[3])
+    assert (want_f[3] >= 0).sum() > 50000
+    g = rs.standard_normal((1, H, W, 1)).astype(np.float32)
+    a = ops().render_depth_grad(_t(g), _t(ver), _t(tri), depth, tind, img)
+    b = ops().render_depth_grad(_t(g), _t(ver), _t(tri), depth, tind, img)
+    plain = torch.empty_like(a)
+    rc = L.fr_render_depth_backward(h.ptr(_t(g)), h.ptr(_t(tri)), h.ptr(tind), h.ptr(plain), 1, nver, tri.shape[1], H, W,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, plain)
+    # float64 sum of the fp32 terms c = g / 3
+    ti = want_f[3].reshape(-1).astype(np.int64)
+    c = (g.reshape(-1) * np.float32(1.0) / np.float32(3.0)).astype(np.float64)
+    want = np.zeros(nver, np.float64)
+    cnt = np.zeros(nver, np.int64)
+    for k in range(3):
+        p = tri[k].astype(np.int64)[ti[ti >= 0]]
+        np.add.at(want, p, c[ti >= 0])
+        np.add.at(cnt, p, 1)
+    got = a.cpu().numpy()[0, 2].astype(np.float64)
+    cmax = np.abs(c).max()
+    bound = 0.5 * np.spacing(np.abs(want).astype(np.float32)).astype(np.float64) + cnt * cmax * 2.0 ** -37
+    assert np.all(np.abs(got - want) <= bound + 1e-300)
+    assert not a[:, :2].any()

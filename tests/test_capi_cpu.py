@@ -56,10 +56,61 @@ def test_validation_codes_without_gpu():
     seg = 504  # triangles (= record slots) per segment
     nseg = (105840 + seg - 1) // seg
     assert L.fr_render_depth_workspace_bytes(64, 53215, 105840, 200, 200) == \
-        64 * nseg * (seg * 16 + 64 * 2) + 2 * 64 * nseg * seg * 16 + nseg * seg * 16  # + pre-validated triangle table
+        64 * nseg * (seg * 16 + 64 * 2) + 2 * 64 * nseg * seg * 16 + (nseg * seg + 1) * 16  # + triangle table + its header
     assert L.fr_render_depth_workspace_bytes(0, 5, 5, 8, 8) == 0
     # workspace too small
     assert L.fr_render_depth_forward(one, one, one, 1, 3, 1, 4, 4, 3, 1, one, one, one, one, nul, 0, nul) == -2
+
+
+def test_options_read_the_environment_once_and_never_on_the_launch_path(monkeypatch):
+    """The launcher knobs take their initial value from the environment ONCE per process; afterwards only fr_set_option
+    changes them -- a later change of os.environ (putenv) must not change behaviour, and no kernel source calls getenv
+    outside that one-time initialisation."""
+    host = pkg("_lib")
+    L = host.lib()
+    before = {k: host.get_option(k) for k in ("FR_EMIT_FILTER", "FR_RENDER_ROWS", "FR_DECODE_NT", "FR_RENDER_IMPL")}
+    monkeypatch.setenv("FR_EMIT_FILTER", "0")
+    monkeypatch.setenv("FR_RENDER_ROWS", "7")
+    monkeypatch.setenv("FR_DECODE_NT", "0")
+    monkeypatch.setenv("FR_RENDER_IMPL", "scan")
+    assert {k: host.get_option(k) for k in before} == before
+    out = (ctypes.c_int * 4)()
+    L.fr_debug_render_geom(64, 105840, 200, 200, 0, out)     # the geometry the launcher would pick: FR_RENDER_ROWS unchanged
+    assert out[0] == 10 or before["FR_RENDER_ROWS"] != 0
+    with host.options(FR_RENDER_ROWS=7):
+        assert host.get_option("FR_RENDER_ROWS") == 7
+    assert host.get_option("FR_RENDER_ROWS") == before["FR_RENDER_ROWS"]
+    assert L.fr_set_option(b"FR_NO_SUCH_KNOB", 1) == -1
+    v = ctypes.c_int(0)
+    assert L.fr_get_option(b"FR_NO_SUCH_KNOB", ctypes.byref(v)) == -1 and L.fr_get_option(b"FR_EMIT_FILTER", None) == -1
+    # getenv appears in exactly one place of the native sources: the one-time option initialisation
+    hits = []
+    csrc = os.path.join(ROOT, "3dfacerecon_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        for i, line in enumerate(open(os.path.join(csrc, fn)), 1):
+            if re.search(r"\bgetenv\s*\(", line):
+                hits.append((fn, i))
+    assert [h[0] for h in hits] == ["fr_capi.hip"], hits
+
+
+def test_binary_only_deployment_loads_without_sources(tmp_path, monkeypatch):
+    """A copied .so without csrc/, include/ or the .srchash sidecar: the identity is read from the hash embedded in the
+    binary, nothing tries to open a source file, and with sources present a sidecar-less library is not declared stale."""
+    host = pkg("_lib")
+    host.lib()
+    real = host.LIB_PATH
+    assert host._built_hash() == host.src_hash()
+    import shutil
+    copy = str(tmp_path / "libfr_hotpath.so")
+    shutil.copy(real, copy)
+    monkeypatch.setattr(host, "LIB_PATH", copy)
+    assert host._built_hash() == host.src_hash() and not host.is_stale()      # no sidecar next to the copy
+    monkeypatch.setattr(host, "HEADERS", [str(tmp_path / "gone.h")])
+    assert host.src_hash() is None and not host.is_stale()
+    monkeypatch.setattr(host, "LIB_PATH", str(tmp_path / "absent.so"))
+    assert host.is_stale()
+    with pytest.raises(RuntimeError):
+        host.compile()
 
 
 def test_render_geometry_window_never_spans_three_strips():
@@ -92,17 +143,19 @@ def test_render_geometry_window_never_spans_three_strips():
 
 def test_packed_basis_size():
     L = pkg("_lib").lib()
-    # two images.  f32: tiles of 16 vertices; 16-wide k groups for shape and exp separately; + packed mu.
-    # Q30 (256-byte aligned after it): 64 ints of column exponents per k-step of 64, then per tile 3 coordinates x
-    # ceil(228 / 16) = 15 live 16-k groups x 4 digits x 256 bytes + a 256-byte payload (mu, row exponents); + 1 KiB slack
+    # the default image.  f32: tiles of 16 vertices; 16-wide k groups for shape and exp separately; + packed mu.
     n = L.fr_decode_packed_basis_bytes(53215, 199, 29)
     tiles, G = (53215 + 15) // 16, 13 + 2
-    f32 = tiles * G * 3 * 64 * 16 + tiles * 3 * 16 * 4
-    q30 = 4 * 64 * 4 + tiles * (3 * 15 * 4 * 256 + 256) + 1024
-    assert n == (f32 + 255) // 256 * 256 + q30
-    # more than 512 coefficients: the Q30 kernels do not take the shape, only the f32 image is kept
+    assert n == tiles * G * 3 * 64 * 16 + tiles * 3 * 16 * 4
+    # the opt-in Q30 image is a buffer of its own: 64 ints of column exponents per k-step of 64, then per tile
+    # 3 coordinates x ceil(228 / 16) = 15 live 16-k groups x 4 digits x 256 bytes + a 256-byte payload (mu, row exponents);
+    # + 1 KiB slack; its staging workspace is S * 16 KiB of parameter digits + Mt [64][12] floats + be [64] ints
+    assert L.fr_decode_q30_image_bytes(53215, 199, 29) == 4 * 64 * 4 + tiles * (3 * 15 * 4 * 256 + 256) + 1024
+    assert L.fr_decode_q30_workspace_bytes(199, 29) == 4 * 16384 + 64 * 12 * 4 + 64 * 4
+    # more than 512 coefficients: the Q30 kernels do not take the shape
     t2 = (100 + 15) // 16
-    assert L.fr_decode_packed_basis_bytes(100, 600, 10) == (t2 * (38 + 1) * 3 * 64 * 16 + t2 * 3 * 16 * 4 + 255) // 256 * 256
+    assert L.fr_decode_packed_basis_bytes(100, 600, 10) == t2 * (38 + 1) * 3 * 64 * 16 + t2 * 3 * 16 * 4
+    assert L.fr_decode_q30_image_bytes(100, 600, 10) == 0 and L.fr_decode_q30_workspace_bytes(600, 10) == 0
 
 
 def test_ops_module_surface_mirrors_reference():

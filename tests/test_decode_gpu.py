@@ -99,16 +99,16 @@ def test_nan_basis_row_does_not_leak(oracle, synth):
 
 
 def test_full_size_batch64(oracle, full_assets, synth):
-    """BASELINE config 2 shape: N=53,215, 199+29 components, B=64.  Oracle check on 2 faces (it needs
-    ~60 ms/face), size-independent properties on the rest."""
+    """BASELINE config 2 shape: N=53,215, 199+29 components, B=64.  Oracle check on ALL 64 faces (~36 ms per face),
+    plus size-independent properties."""
     A = full_assets
     P = synth.sample_params_batch(64, beta=0.7, seed=3456)
     net = net_mod().FaceRecNet(mesh_data=A, batch_size=64, im_size=200)
     R = oracle.rotation_matrix_batch(P[:, :3])
     got = _decode_gpu(net, P, R)
-    for b in (0, 63):
-        want = oracle.decode_3dmm(P[b:b + 1], A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R[b:b + 1])
-        np.testing.assert_array_equal(got[b:b + 1], want)
+    want = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R)
+    for b in range(64):
+        np.testing.assert_array_equal(got[b], want[b], err_msg="face %d" % b)
     # determinism + independence of the batch composition (each column is its own fmaf chain)
     np.testing.assert_array_equal(_decode_gpu(net, P, R), got)
     perm = np.random.RandomState(1).permutation(64)
@@ -122,3 +122,22 @@ def test_full_size_batch64(oracle, full_assets, synth):
     assert np.max(np.abs((got2[:, 0] - got[:, 0]) - 8.0)) < 1e-4
     assert np.max(np.abs((got2[:, 1] - got[:, 1]) - 4.0)) < 1e-4
     np.testing.assert_array_equal(got2[:, 2], got[:, 2])
+
+
+@pytest.mark.parametrize("knobs", [{"FR_DECODE_NT": 0}, {"FR_DECODE_NBW": 1}, {"FR_DECODE_WAVES": 8}, {"FR_DECODE_IMPL": 1},
+                                   {"FR_DECODE_WIDE": 0}])
+def test_launcher_knobs_do_not_change_a_bit(oracle, synth, knobs):
+    """The decode launcher's A/B knobs (fr_set_option; the environment is read once per process) select other schedules of
+    the same arithmetic: the model's basis shape at B = 70 (one 128-column pass, or 64 + 6 with FR_DECODE_WIDE=0) stays
+    bit-identical to the default and to the oracle."""
+    from conftest import pkg
+    A = synth.make_assets(9, 11, 199, 29, patch=None, seed_basis=3)
+    B = 70
+    P = _rand_params(np.random.RandomState(6), B, 199, 29, 200)
+    R = oracle.rotation_matrix_batch(P[:, :3])
+    net = net_mod().FaceRecNet(mesh_data=A, batch_size=B, im_size=200)
+    base = _decode_gpu(net, P, R)
+    np.testing.assert_array_equal(base, oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R))
+    with pkg("_lib").options(**knobs):
+        np.testing.assert_array_equal(_decode_gpu(net, P, R), base)
+        np.testing.assert_array_equal(_decode_gpu(net, P[:33], R[:33]), base[:33])

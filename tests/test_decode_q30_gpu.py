@@ -16,11 +16,12 @@ Q30, F32 = 0, 1
 
 @pytest.fixture()
 def q30_mode():
-    L = pkg("_lib").lib()
-    prev = L.fr_decode_get_arith()
-    assert L.fr_decode_set_arith(Q30) == 0 and L.fr_decode_get_arith() == Q30
-    yield L
-    L.fr_decode_set_arith(prev)
+    h = pkg("_lib")
+    prev = h.decode_arith()
+    h.set_decode_arith(Q30)
+    assert h.decode_arith() == Q30
+    yield h
+    h.set_decode_arith(prev)
 
 
 def _decode_gpu(net, P, R=None):
@@ -42,9 +43,11 @@ def _rand_params(rs, B, ns, ne, im):
 
 
 def test_setter_rejects_unknown_mode():
-    L = pkg("_lib").lib()
-    prev = L.fr_decode_get_arith()
-    assert L.fr_decode_set_arith(7) == -1 and L.fr_decode_get_arith() == prev
+    h = pkg("_lib")
+    prev = h.decode_arith()
+    with pytest.raises(ValueError):
+        h.set_decode_arith(7)
+    assert h.decode_arith() == prev
 
 
 @pytest.mark.parametrize("gu,gv,ns,ne,B", [
@@ -151,9 +154,9 @@ def test_full_size_batch64(q30_mode, oracle, full_assets, synth):
     P2[:, 6] = 1.0
     I = np.tile(np.eye(3, dtype=np.float32).reshape(1, 3, 3), (4, 1, 1))
     vq = _decode_gpu(net, P2, I)
-    q30_mode.fr_decode_set_arith(F32)
+    q30_mode.set_decode_arith(F32)
     vc = _decode_gpu(net, P2, I)
-    q30_mode.fr_decode_set_arith(Q30)
+    q30_mode.set_decode_arith(Q30)
     Ab = np.concatenate([A["pc_shape"], A["pc_exp"]], 1).astype(np.float64)
     vt = (A["mu"].reshape(-1).astype(np.float64)[None] + P2[:, 7:].astype(np.float64) @ Ab.T).reshape(4, 3, -1)
     cr = vt.astype(np.float32)

@@ -35,7 +35,13 @@ def _worker(rank, world, port, q):
     t = d.max_over_ranks(0.25 * (rank + 1))
     faces = d.sum_over_ranks(hi - lo)
     d.barrier()
-    q.put((rank, lo, hi, t, faces, float(P.sum())))
+    # the bench's strong-scaling partition of ONE 64-face batch, and what the process group reports about itself
+    first, nloc, nglob = d.bench_partition(64, rank, world, "strong")
+    wfirst, wloc, wglob = d.bench_partition(64, rank, world, "weak")
+    info = d.describe()
+    times = d.gather_over_ranks(0.1 * (rank + 1))
+    owned = d.sum_over_ranks(nloc)
+    q.put((rank, lo, hi, t, faces, float(P.sum()), (first, nloc, nglob, wfirst, wloc, wglob, info, times, owned)))
     d.finalize()
 
 
@@ -50,7 +56,11 @@ def test_two_rank_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, lo0, hi0, t0, f0, s0), (r1, lo1, hi1, t1, f1, s1) = res
+    (r0, lo0, hi0, t0, f0, s0, x0), (r1, lo1, hi1, t1, f1, s1, x1) = res
+    # strong scaling: rank 0 owns faces [0, 32), rank 1 [32, 64) of the one 64-face batch; weak: 64 each, 128 in all
+    assert x0[:6] == (0, 32, 64, 0, 64, 128) and x1[:6] == (32, 32, 64, 64, 64, 128)
+    assert x0[6] == x1[6] == {"backend": "gloo", "world_size": 2, "ranks_reporting": 2}
+    assert x0[7] == x1[7] == [0.1, 0.2] and x0[8] == x1[8] == 64
     assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)          # disjoint, covering, no overlap
     assert t0 == t1 == 0.5                                 # MAX over ranks
     assert f0 == f1 == 7                                   # every face counted once
@@ -61,4 +71,7 @@ def test_single_process_helpers_are_noops():
     import importlib
     d = importlib.import_module("3dfacerecon_amd.utils.dist")
     assert d.max_over_ranks(1.5) == 1.5 and d.sum_over_ranks(3) == 3.0
+    assert d.gather_over_ranks(2.5) == [2.5] and d.describe()["world_size"] == 1
+    assert d.bench_partition(64, 0, 1, "strong") == (0, 64, 64) and d.bench_partition(64, 3, 8, "strong") == (24, 8, 64)
+    assert d.bench_partition(10, 7, 8, "strong") == (9, 1, 10) and d.bench_partition(3, 7, 8, "strong")[1] == 0
     d.barrier()

@@ -120,17 +120,17 @@ def test_decode_both_arithmetics(oracle, synth, seed):
     P[:, 7 + ns:] = rs.uniform(-1.5, 1.5, (B, ne))
     R = oracle.rotation_matrix_batch(P[:, :3])
     net = net_mod().FaceRecNet(mesh_data=A, batch_size=B, im_size=200)
-    L = pkg("_lib").lib()
-    prev = L.fr_decode_get_arith()
+    h = pkg("_lib")
+    prev = h.decode_arith()
     try:
         for mode, q30 in ((1, False), (0, True)):
-            L.fr_decode_set_arith(mode)
+            h.set_decode_arith(mode)
             got = net.vertices_transform(torch.as_tensor(P, device="cuda:0"), R=torch.as_tensor(R, device="cuda:0"))
             torch.cuda.synchronize()
             want = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R, q30=q30)
             np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg="seed %d %s" % (seed, "q30" if q30 else "f32"))
     finally:
-        L.fr_decode_set_arith(prev)
+        h.set_decode_arith(prev)
 
 
 @pytest.mark.parametrize("seed", range(max(1, N_RENDER // 4)))

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, kat_inputs
-from ref_bruteforce import render_depth_bruteforce
+from ref_bruteforce import render_depth_bruteforce, render_depth_grad_bruteforce
 
 
 @pytest.fixture(scope="module")
@@ -130,3 +130,79 @@ def test_one_full_size_face(oracle, pit, full_assets, synth):
     want = render_depth_bruteforce(V, A["tri"], A["vertex"][None], 200, 200, pit)
     assert (want[3] >= 0).mean() > 0.2
     _eq(oracle.render_depth(V, A["tri"], A["vertex"][None], 200, 200), want, "full-size")
+
+
+# ---- the backward as a WHOLE function -----------------------------------------------------
+# render_depth_grad_bruteforce (tests/ref_bruteforce.py) is a plain-Python restatement of render_depth_op.cc:344-366 --
+# row-major pixel order, fp32 `g * 1.0f / 3.0f`, sequential fp32 `+=` -- that shares no code with oracle/fr_oracle.c; the
+# oracle's backward is held to it BIT FOR BIT (one fixed summation order on both sides).  No reference binary is involved
+# (the loop has no helper function to compile), so these tests run on any box.
+
+def _bits_equal(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _grad_case(rs, B, H, W, kind):
+    if kind == "unit":
+        return np.ones((B, H, W, 1), np.float32)
+    if kind == "wide":       # 12 decades of magnitude, both signs: the order of the fp32 adds matters
+        return (rs.standard_normal((B, H, W, 1)) * np.exp(rs.uniform(-14, 14, (B, H, W, 1)))).astype(np.float32)
+    g = rs.standard_normal((B, H, W, 1)).astype(np.float32)
+    g[rs.rand(B, H, W, 1) < 0.1] = 0.0
+    return g
+
+
+@pytest.mark.parametrize("kind", ["unit", "normal", "wide"])
+def test_backward_whole_function_random_scenes(oracle, kind):
+    rs = np.random.RandomState(77)
+    for B, nver, ntri, H, W, scale in ((2, 60, 150, 16, 18, 2.0), (1, 300, 800, 40, 33, 1.2), (3, 40, 60, 9, 7, 6.0)):
+        ver, tri, tex = _random_scene(rs, B, nver, ntri, H, W, scale)
+        tri_ind = oracle.render_depth(ver, tri, tex, H, W)[3]
+        assert (tri_ind >= 0).mean() > 0.05
+        g = _grad_case(rs, B, H, W, kind)
+        want = render_depth_grad_bruteforce(g, tri, tri_ind, nver)
+        got = oracle.render_depth_grad(g, tri, tri_ind, nver)
+        assert _bits_equal(got, want), (kind, B, nver, int((got != want).sum()))
+        assert not got[:, :2].any()                       # x and y rows carry no gradient (:359-363)
+
+
+def test_backward_whole_function_ties_bad_ids_and_hand_made_tri_ind(oracle):
+    """Many pixels on few triangles (long per-vertex sums: the order of the adds is what is being pinned), shared
+    vertices, out-of-range / negative / fractional / NaN tri_ind values, triangles with ids outside [0, nver)."""
+    rs = np.random.RandomState(5)
+    B, H, W, nver = 2, 23, 19, 12
+    tri = np.array([[0, 1, 2, 3, 0, 11, 12, -1, 5],
+                    [1, 2, 3, 4, 5, 10, 3, 2, 5.9],
+                    [2, 3, 4, 0, 6, 9, 1, 1, 6.2]], np.float32)      # triangle 6: id 12 = nver (bad), 7: -1 (bad), 8: fractional
+    ntri = tri.shape[1]
+    tri_ind = rs.randint(-1, ntri, (B, H, W, 1)).astype(np.float32)
+    tri_ind[0, 0, 0, 0] = np.nan
+    tri_ind[0, 0, 1, 0] = ntri            # one past the end
+    tri_ind[0, 0, 2, 0] = 3.9             # (int) truncates to 3
+    tri_ind[0, 0, 3, 0] = -0.5            # truncates to 0 -> triangle 0
+    tri_ind[0, 0, 4, 0] = 1e20            # out of int range
+    tri_ind[1, :, :, 0] = 4               # a whole face on ONE triangle: 437 sequential adds per vertex
+    for kind in ("normal", "wide"):
+        g = _grad_case(rs, B, H, W, kind)
+        want = render_depth_grad_bruteforce(g, tri, tri_ind, nver)
+        got = oracle.render_depth_grad(g, tri, tri_ind, nver)
+        assert _bits_equal(got, want), kind
+    g = _grad_case(rs, B, H, W, "normal")
+    g[1, 3, 3, 0] = np.inf
+    g[0, 5, 5, 0] = np.nan
+    want = render_depth_grad_bruteforce(g, tri, tri_ind, nver)
+    got = oracle.render_depth_grad(g, tri, tri_ind, nver)
+    assert np.array_equal(got, want, equal_nan=True) and np.isnan(got).any()
+
+
+def test_backward_whole_function_one_full_size_face(oracle, full_assets, synth):
+    """BFM-scale mesh, 200x200, the bench's parameters: 40,000 pixels through the Python loop (a few seconds)."""
+    A = full_assets
+    P = synth.sample_params_batch(1, beta=0.7, seed=3456)
+    V = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0)
+    tri_ind = oracle.render_depth(V, A["tri"], A["vertex"][None], 200, 200)[3]
+    g = _grad_case(np.random.RandomState(9), 1, 200, 200, "wide")
+    want = render_depth_grad_bruteforce(g, A["tri"], tri_ind, V.shape[2])
+    got = oracle.render_depth_grad(g, A["tri"], tri_ind, V.shape[2])
+    assert _bits_equal(got, want)
+    assert np.count_nonzero(got[0, 2]) > 5000

@@ -15,9 +15,9 @@ def test_params_to_depth_q30(oracle, full_assets, synth):
     its depth against the float64 decode recorded next to the f32 chain's (a correctly rounded blend leaves only the
     fp32 pose product's roundings)."""
     A = full_assets
-    L = pkg_mod("_lib").lib()
-    prev = L.fr_decode_get_arith()
-    L.fr_decode_set_arith(0)
+    h = pkg_mod("_lib")
+    prev = h.decode_arith()
+    h.set_decode_arith(0)
     try:
         P = synth.sample_params_batch(2, beta=0.7, seed=3456)
         R = oracle.rotation_matrix_batch(P[:, :3])
@@ -26,7 +26,7 @@ def test_params_to_depth_q30(oracle, full_assets, synth):
         outs = ops().render_depth(V, net.tri, net.vertex_code, torch.zeros((2, 200, 200, 3), device="cuda:0"))
         got = tuple(o.cpu().numpy() for o in outs)
     finally:
-        L.fr_decode_set_arith(prev)
+        h.set_decode_arith(prev)
     Vo = oracle.decode_3dmm_q30(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R)
     assert_render_equal(got, oracle.render_depth(Vo, A["tri"], A["vertex"][None], 200, 200), "params->depth (q30)")
     V64 = oracle.decode_3dmm_f64(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0)
@@ -170,6 +170,139 @@ def test_plan_matches_operator_surface(full_assets, synth):
     got2 = [o.clone() for o in plan.replay(P)]
     for g, w in zip(got2, want):
         assert torch.equal(g, w)
+
+
+def test_plan_route_full_batch64_every_face_against_the_oracle(oracle, full_assets, synth):
+    """The route bench.py times -- DecodeRenderPlan: fr_decode_3dmm -> fr_render_depth_forward_phases(3) on a triangle
+    table packed once -- at the bench's own batch (64 faces, seed 3456), EVERY face against the oracle: the render planes
+    bit for bit on the plan's own vertices, the decode (in-kernel float64 rotation) within 2 ulp / 99 % equal of the spec
+    oracle, and bit for bit through the same kernel with the host rotation; replay through the hipGraph and a second
+    eager step reproduce the same bits."""
+    pipe = __import__("importlib").import_module("3dfacerecon_amd.pipeline")
+    A = full_assets
+    B = 64
+    P = synth.sample_params_batch(B, beta=0.7, seed=3456)
+    net = net_mod().FaceRecNet(mesh_data=A, batch_size=B, im_size=200)
+    plan = pipe.DecodeRenderPlan(net, B, 200, 200)
+    got = [o.clone() for o in plan.step(torch.as_tensor(P, device="cuda:0"))]
+    torch.cuda.synchronize()
+    V = plan.vertex_proj.cpu().numpy()
+    want = oracle.render_depth(V, A["tri"], A["vertex"][None], 200, 200)
+    for b in range(B):
+        assert_render_equal(tuple(g[b:b + 1].cpu().numpy() for g in got), tuple(w[b:b + 1] for w in want), "plan face %d" % b)
+    assert (want[3] >= 0).mean() > 0.2
+    R = oracle.rotation_matrix_batch(P[:, :3])
+    Vo = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R)
+    Vr = net.vertices_transform(torch.as_tensor(P, device="cuda:0"), R=torch.as_tensor(R, device="cuda:0")).cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(Vr[b], Vo[b], err_msg="decode (host R) face %d" % b)
+    a, o = V.view(np.int32).astype(np.int64), Vo.view(np.int32).astype(np.int64)
+    ulp = np.abs(np.where(a < 0, -(a & 0x7FFFFFFF), a) - np.where(o < 0, -(o & 0x7FFFFFFF), o))
+    assert ulp.max() <= 2 and (ulp == 0).mean() >= 0.99
+    # the same bits from a second eager step and from the captured graph
+    for again in (plan.step(), plan.replay()):
+        torch.cuda.synchronize()
+        for g, w in zip(again, got):
+            assert torch.equal(g, w)
+    # the operator surface (allocating route) agrees with the plan on all 64 faces
+    Vs = net.vertices_transform(torch.as_tensor(P, device="cuda:0"))
+    outs = ops().render_depth(Vs, net.tri, net.vertex_code, torch.zeros((B, 200, 200, 3), device="cuda:0"))
+    outs2 = ops().render_depth(Vs, net.tri, net.vertex_code, torch.zeros((B, 200, 200, 3), device="cuda:0"))  # cached table
+    for g, g2, w in zip(outs, outs2, got):
+        assert torch.equal(g, w) and torch.equal(g2, w)
+
+
+def test_q30_plan_capture_and_replay(oracle, full_assets, synth):
+    """with the Q30 arithmetic selected, capture() / replay() must work -- the staging buffer
+    is the plan's own, nothing is allocated at launch time -- and the replayed decode is the Q30 spec's, bit for bit."""
+    pipe = __import__("importlib").import_module("3dfacerecon_amd.pipeline")
+    h = pkg_mod("_lib")
+    A = full_assets
+    prev = h.decode_arith()
+    h.set_decode_arith(h.DECODE_ARITH_Q30)
+    try:
+        net = net_mod().FaceRecNet(mesh_data=A, batch_size=3, im_size=200)
+        assert net._basis._qimage is None                    # nothing of Q30 exists before it is used
+        P = synth.sample_params_batch(3, beta=0.7, seed=21)
+        plan = pipe.DecodeRenderPlan(net, 3, 200, 200)
+        assert plan.q30 and net._basis._qimage is not None
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):                        # capture on a stream the plan has never launched on
+            plan.params.copy_(torch.as_tensor(P, device="cuda:0"))
+            plan.capture()
+            outs = [o.clone() for o in plan.replay()]
+            Vq = plan.vertex_proj.clone()
+        side.synchronize()
+        torch.cuda.synchronize()
+    finally:
+        h.set_decode_arith(prev)
+    # in-kernel rotation: compare through the host-R route for the bit-exact leg
+    R = oracle.rotation_matrix_batch(P[:, :3])
+    Vo = oracle.decode_3dmm_q30(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R)
+    a, o = Vq.cpu().numpy().view(np.int32).astype(np.int64), Vo.view(np.int32).astype(np.int64)
+    ulp = np.abs(np.where(a < 0, -(a & 0x7FFFFFFF), a) - np.where(o < 0, -(o & 0x7FFFFFFF), o))
+    assert ulp.max() <= 2 and (ulp == 0).mean() >= 0.99
+    want = oracle.render_depth(Vq.cpu().numpy(), A["tri"], A["vertex"][None], 200, 200)
+    assert_render_equal(tuple(t.cpu().numpy() for t in outs), want, "q30 replay")
+    # a default-arithmetic net built afterwards still holds no Q30 image
+    net2 = net_mod().FaceRecNet(mesh_data=A, batch_size=1, im_size=200)
+    net2.vertices_transform(torch.as_tensor(P[:1], device="cuda:0"))
+    assert net2._basis._qimage is None
+
+
+def test_workspace_cache_is_bounded_and_skipped_under_capture(small_assets):
+    """ops._WS_CACHE: at most WS_CACHE_MAX entries however many streams call the op, clear_workspace_cache() empties it,
+    and a call made while a stream is being captured does not touch it (the graph keeps its own buffer)."""
+    o = ops()
+    A = small_assets
+    net = net_mod().FaceRecNet(mesh_data=A, batch_size=2, im_size=40)
+    rs = np.random.RandomState(4)
+    P = np.zeros((2, net.ndim), np.float32)
+    P[:, 3:5] = 20
+    P[:, 6] = 2e-4
+    P[:, 7:7 + net.ndim_shape] = rs.uniform(0, 1e4, (2, net.ndim_shape))
+    V = net.vertices_transform(torch.as_tensor(P, device="cuda:0"))
+    img = torch.zeros((2, 40, 40, 3), device="cuda:0")
+    ref = [t.clone() for t in o.render_depth(V, net.tri, net.vertex_code, img)]
+    o.clear_workspace_cache()
+    assert len(o._WS_CACHE) == 0
+    streams = [torch.cuda.Stream() for _ in range(o.WS_CACHE_MAX + 3)]
+    torch.cuda.synchronize()
+    for st in streams:
+        with torch.cuda.stream(st):
+            outs = o.render_depth(V, net.tri, net.vertex_code, img)
+            outs2 = o.render_depth(V, net.tri, net.vertex_code, img)        # second call: cached triangle table
+        st.synchronize()
+        for a, b, c in zip(outs, outs2, ref):
+            assert torch.equal(a, c) and torch.equal(b, c)
+        assert len(o._WS_CACHE) <= o.WS_CACHE_MAX
+    assert len(o._WS_CACHE) == o.WS_CACHE_MAX
+    # an in-place change of the triangle list is seen (torch's version counter), not served from the cached table
+    tri2 = net.tri.clone()
+    o.render_depth(V, tri2, net.vertex_code, img)
+    tri2[:, 0] = tri2[:, 1]
+    want2 = o.render_depth(V, tri2.clone(), net.vertex_code, img)
+    got2 = o.render_depth(V, tri2, net.vertex_code, img)
+    for a, b in zip(got2, want2):
+        assert torch.equal(a, b)
+    o.clear_workspace_cache()
+    n0 = len(o._WS_CACHE)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        o.render_depth(V, net.tri, net.vertex_code, img)    # warm-up outside the capture
+        side.synchronize()
+        before = dict(o._WS_CACHE)
+        with torch.cuda.graph(g, stream=side):
+            cap = o.render_depth(V, net.tri, net.vertex_code, img)
+        assert dict(o._WS_CACHE) == before                  # the capture neither added nor replaced an entry
+        o.clear_workspace_cache()                           # ... and survives the cache being dropped
+        g.replay()
+    side.synchronize()
+    torch.cuda.synchronize()
+    for a, c in zip(cap, ref):
+        assert torch.equal(a, c)
+    assert n0 == 0
 
 
 def test_compute_abedo_image_and_mat_assets(tmp_path, small_assets):

@@ -258,8 +258,8 @@ def test_full_size_face_bit_exact(oracle, full_assets, synth):
 
 
 def test_batch64_properties(full_assets, synth, oracle):
-    """BASELINE config 2 size (B=64): determinism, batch-permutation equivariance, and agreement of a few
-    faces with the oracle (the oracle needs ~13 ms/face, so 3 faces)."""
+    """BASELINE config 2 size (B=64): determinism, batch-permutation equivariance, and agreement of ALL 64 faces with
+    the oracle (2.3 ms per face)."""
     A = full_assets
     P = synth.sample_params_batch(4, beta=0.7, seed=99)
     V4 = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0)
@@ -272,9 +272,9 @@ def test_batch64_properties(full_assets, synth, oracle):
     perm = rs.permutation(64)
     gotp = render_gpu(V[perm], A["tri"], A["vertex"], 200, 200)
     assert_render_equal(gotp, tuple(g[perm] for g in got1), "batch permutation")
-    for b in (0, 31, 63):
-        want = oracle.render_depth(V[b:b + 1], A["tri"], A["vertex"][None], 200, 200)
-        assert_render_equal(tuple(g[b:b + 1] for g in got1), want, "face %d" % b)
+    want = oracle.render_depth(V, A["tri"], A["vertex"][None], 200, 200)
+    for b in range(64):
+        assert_render_equal(tuple(g[b:b + 1] for g in got1), tuple(w[b:b + 1] for w in want), "face %d" % b)
     # triangle-order invariance of depth: reversing the triangle list changes tri_ind but not the depth map,
     # and coverage stays identical
     tri_rev = np.ascontiguousarray(A["tri"][:, ::-1])
@@ -296,31 +296,23 @@ def test_div3_matches_division_on_every_fp32():
     assert int(cnt.item()) == 0
 
 
-@pytest.mark.parametrize("env", [{"FR_RENDER_IMPL": "scan"}, {"FR_RENDER_ROWS": "1"}, {"FR_RENDER_ROWS": "3"},
-                                 {"FR_RENDER_ROWS": "7"}, {"FR_EMIT_FILTER": "0"}, {"FR_EMIT_FILTER": "1"},
-                                 {"FR_EMIT_FILTER": "2"}, {"FR_RESOLVE_OPT": "0"}])
+@pytest.mark.parametrize("env", [{"FR_RENDER_IMPL": 1}, {"FR_RENDER_ROWS": 1}, {"FR_RENDER_ROWS": 3},
+                                 {"FR_RENDER_ROWS": 7}, {"FR_EMIT_FILTER": 0}, {"FR_EMIT_FILTER": 1},
+                                 {"FR_EMIT_FILTER": 2}, {"FR_RESOLVE_OPT": 0}, {"FR_RESOLVE_BLOCK": 512},
+                                 {"FR_RESOLVE_BLOCK": 1024}])
 def test_fallback_and_row_override_paths(oracle, env):
     """render_strip_kernel (every bin scans every triangle) is the path for shapes the binned rasteriser rejects; the
     tuning knob FR_RENDER_ROWS below the hit-window height must route there too, larger overrides
     stay binned.  The A/B knobs of the fast paths (FR_EMIT_FILTER: 0 = every pixel through the reference's fp64 sequence,
     1 = certified fp32 test only, 2 = phase-A pre-cull only; FR_RESOLVE_OPT=0 = two-pass resolver) must not change a bit
-    either.  All bit-exact."""
-    import os
+    either.  All bit-exact.  The knobs are set through fr_set_option (the environment is read once per process)."""
     rs = np.random.RandomState(11)
     scenes = [_random_scene(rs, 3, 300, 700, 33, 47, 2.0) + (33, 47), _random_scene(rs, 2, 400, 900, 64, 64, 6.0) + (64, 64)]
     ver, tri, tex = _subpixel_mesh(rs, 4, 40, 40, 56, 56, 0.45)
     scenes.append((ver, tri, tex, 40, 40))
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    with pkg("_lib").options(**env):
         for ver, tri, tex, H, W in scenes:
             assert_render_equal(render_gpu(ver, tri, tex, H, W), oracle.render_depth(ver, tri, tex, H, W), str(env))
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def test_very_wide_image_takes_the_scan_path(oracle):
@@ -383,3 +375,51 @@ def test_certified_fp32_inside_filter_adversarial(oracle):
     t5 = np.arange(15, dtype=np.float32).reshape(5, 3).T.copy()
     x5 = rs.uniform(0, 1, (1, 3, 15)).astype(np.float32)
     assert_render_equal(render_gpu(v, t5, x5, H, W), oracle.render_depth(v, t5, x5, H, W), "extremes")
+
+
+def test_emit_phase_refuses_a_table_packed_for_other_arguments(oracle):
+    """fr_render_depth_forward_phases(3) consumes whatever triangle table the workspace holds.  The table
+    now names the (nver, ntri) it was packed for; an emit phase handed a table that was never packed, or packed for
+    another shape, treats every triangle as invalid: pure background planes, no out-of-bounds gather, no error code."""
+    import ctypes
+    h = pkg("_lib")
+    L = h.lib()
+    rs = np.random.RandomState(21)
+    H = W = 48
+    dev = torch.device("cuda:0")
+
+    def scene(nver, ntri):
+        ver = np.empty((2, 3, nver), np.float32)
+        ver[:, 0] = rs.uniform(0, W, (2, nver))
+        ver[:, 1] = rs.uniform(0, H, (2, nver))
+        ver[:, 2] = rs.uniform(-5, 5, (2, nver))
+        tri = rs.randint(0, nver, (3, ntri)).astype(np.float32)
+        tex = rs.uniform(0, 1, (2, 3, nver)).astype(np.float32)
+        return ver, tri, tex
+
+    def run(ver, tri, tex, ws, phases):
+        t = [torch.as_tensor(a, device=dev) for a in (ver, tri, tex)]
+        outs = [torch.full((2, H, W, c), 7.0, device=dev) for c in (1, 3, 3, 1)]
+        nws = L.fr_render_depth_workspace_bytes(2, ver.shape[2], tri.shape[1], H, W)
+        assert ws.numel() >= nws
+        rc = L.fr_render_depth_forward_phases(h.ptr(t[0]), h.ptr(t[1]), h.ptr(t[2]), 2, ver.shape[2], tri.shape[1], H, W, 3,
+                                              2, h.ptr(outs[0]), h.ptr(outs[1]), h.ptr(outs[2]), h.ptr(outs[3]), h.ptr(ws),
+                                              nws, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), phases)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return tuple(o.cpu().numpy() for o in outs)
+
+    a = scene(500, 900)
+    b = scene(500, 1400)     # another ntri: the table sits elsewhere in the workspace and names other sizes
+    ws = torch.zeros((L.fr_render_depth_workspace_bytes(2, 500, 1400, H, W) + 64,), dtype=torch.uint8, device=dev)
+    empty = oracle.render_depth(a[0], np.zeros((3, 0), np.float32), a[2], H, W)
+    assert_render_equal(run(*a, ws, 3), empty, "never packed")                 # zeroed workspace, no pack phase
+    want_a = oracle.render_depth(*a, H, W)
+    assert (want_a[3] >= 0).mean() > 0.3
+    assert_render_equal(run(*a, ws, 7), want_a, "packed + rendered")
+    assert_render_equal(run(*a, ws, 3), want_a, "table reused")
+    assert_render_equal(run(*b, ws, 7), oracle.render_depth(*b, H, W), "other shape")
+    # a workspace whose only table was packed for ANOTHER shape (pack phase alone: bit 4), then emit + resolve for `a`
+    ws2 = torch.zeros_like(ws)
+    run(*b, ws2, 4)
+    assert_render_equal(run(*a, ws2, 3), empty, "table of another shape")
