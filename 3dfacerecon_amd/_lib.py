@@ -8,7 +8,9 @@ import hashlib
 import os
 import shutil
 import subprocess
+import sys
 import threading
+import types
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
@@ -192,7 +194,9 @@ def lib():
 
 # ---- host-side choices --------------------------------------------------------------------------------------------
 DECODE_ARITH_Q30, DECODE_ARITH_F32 = 0, 1
-_decode_arith = None
+# This file is loaded under two module names (the package's `3dfacerecon_amd._lib`, and by path from the reference-style
+# flat modules rendering_layer/ops.py, nets/network.py, pipeline.py): process-wide choices live in ONE shared namespace.
+_STATE = sys.modules.setdefault("_fr_hotpath_state", types.SimpleNamespace(decode_arith=None))
 
 
 def decode_arith():
@@ -200,17 +204,15 @@ def decode_arith():
     use: DECODE_ARITH_F32 (default: fr_decode_3dmm, the k-ordered fmaf chain) or DECODE_ARITH_Q30 (fr_decode_3dmm_q30,
     the frozen exact-fixed-point experiment; its image and workspace are built on first use).  Process-wide; the initial
     value comes from the environment variable FR_DECODE_ARITH = "f32" | "q30", read once."""
-    global _decode_arith
-    if _decode_arith is None:
-        _decode_arith = DECODE_ARITH_Q30 if os.environ.get("FR_DECODE_ARITH") == "q30" else DECODE_ARITH_F32
-    return _decode_arith
+    if _STATE.decode_arith is None:
+        _STATE.decode_arith = DECODE_ARITH_Q30 if os.environ.get("FR_DECODE_ARITH") == "q30" else DECODE_ARITH_F32
+    return _STATE.decode_arith
 
 
 def set_decode_arith(mode):
-    global _decode_arith
     if mode not in (DECODE_ARITH_Q30, DECODE_ARITH_F32):
         raise ValueError("decode arithmetic must be DECODE_ARITH_F32 or DECODE_ARITH_Q30")
-    _decode_arith = mode
+    _STATE.decode_arith = mode
 
 
 def set_option(name, value):

@@ -313,7 +313,8 @@ __device__ __forceinline__ void ring_wait(f32x4& slot) {
 // leaves VGPRs free on purpose: the 8-wave form (WPE = 4: <= 128 VGPRs, half the register file) lets the render
 // kernels of the previous batch share the CU with the decode of the next one (pipeline.py, PipelinedPlan).
 // NT: the basis stream is requested with the non-temporal hint (read once per launch by one CU pair of waves).
-template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64, int WPE = DEC_WAVES / 4, bool NT = false, class PR = NoProbe>
+template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64, int WPE = DEC_WAVES / 4, bool NT = false, class PR = NoProbe,
+          bool TILED = false, bool PERM = false>
 __global__ __launch_bounds__(DEC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void decode_ring_kernel(DecodeArgs a) {
     PR pr;
@@ -441,7 +442,7 @@ void decode_ring_kernel(DecodeArgs a) {
         }
         pr.item_mfma_done();
         if ((PR::bits & 32) == 0 || c[0][0][0] + c[1][0][1] + c[2][NBW - 1][2] == 12345.678f)
-            decode_store<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
+            decode_store<NBW, TILED, PERM>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
         pr.item_end();
 #pragma unroll
         for (int cc = 0; cc < 3; cc++)
@@ -529,6 +530,7 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
     a.out = vertex_proj;
     a.B = B; a.N = N; a.ns = n_shape; a.ne = n_exp;
     a.im_size = im_size;
+    a.tiled = 0;
     const int cus = fr_device_cu_count();
     const bool loop_env = opt(OPT_DECODE_IMPL) == 1;
     const bool wide_off = opt(OPT_DECODE_WIDE) == 0;

@@ -18,6 +18,7 @@ import importlib.util
 import os
 import sys
 import threading
+import weakref
 
 import torch
 
@@ -61,21 +62,24 @@ _host().lib()
 #   * never used while the current stream is being captured into a hipGraph: a captured launch must not point at a buffer
 #     the cache may later replace, so the capture gets a buffer of its own from the graph's memory pool;
 #   * guarded by a lock (autograd worker threads call the forward too).
-# Each entry also remembers which triangle list its pre-validated triangle table (pack_tri_kernel) was built from --
-# (data_ptr, torch version counter, geometry) -- so a loop that renders with the same `tri` tensor every call (the
-# reference makes it a tf.constant, network.py:178) packs it once, not once per call.  The version counter sees in-place
-# torch writes; a caller that rewrites the tensor's memory behind torch's back must call clear_workspace_cache().
+# Each entry also remembers which triangle list its pre-validated triangle table (pack_tri_kernel) was built from -- the
+# tensor OBJECT (held weakly), its torch version counter and the geometry -- so a loop that renders with the same `tri`
+# tensor every call (the reference makes it a tf.constant, network.py:178) packs it once, not once per call.  A new tensor
+# is never mistaken for an old one whose memory the caching allocator handed out again (object identity, not data_ptr);
+# the version counter sees in-place torch writes; a caller that rewrites the tensor's memory behind torch's back must call
+# clear_workspace_cache().
 WS_CACHE_MAX = 4
 _WS_CACHE = collections.OrderedDict()
 _WS_LOCK = threading.Lock()
 
 
 class _WsEntry:
-    __slots__ = ("buf", "tri_key")
+    __slots__ = ("buf", "tri_ref", "tri_key")
 
     def __init__(self, buf):
         self.buf = buf
-        self.tri_key = None
+        self.tri_ref = None   # weakref to the tensor the table was packed from
+        self.tri_key = None   # (its version counter, its data_ptr) + geometry
 
 
 def clear_workspace_cache():
@@ -102,9 +106,10 @@ def _workspace(dev, nbytes):
 
 def _render_phases(ent, cached, tri_c, geom):
     """7 (pack + emit + resolve) or 3 when the entry's triangle table was packed from this very list for this geometry."""
-    key = (tri_c.data_ptr(), tri_c._version) + geom
-    if cached and ent.tri_key == key:
+    key = (tri_c._version, tri_c.data_ptr()) + geom
+    if cached and ent.tri_ref is not None and ent.tri_ref() is tri_c and ent.tri_key == key:
         return 3
+    ent.tri_ref = weakref.ref(tri_c) if cached else None
     ent.tri_key = key if cached else None
     return 7
 
@@ -224,7 +229,7 @@ class _RenderingLayerFused(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws_bytes = L.fr_render_depth_workspace_bytes(B, nver, ntri, H, W)
             ent, _ = _workspace(dev, ws_bytes)
-            ent.tri_key = None   # (this entry point always repacks the triangle table)
+            ent.tri_ref = ent.tri_key = None   # (this entry point always repacks the triangle table)
             rc = L.fr_rendering_layer_forward(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), h.ptr(img_c), B, nver, ntri, H, W,
                                               tex_batch, h.ptr(net_in), h.ptr(depth_img), h.ptr(depth), h.ptr(tri_ind),
                                               h.ptr(ent.buf), ws_bytes, h.stream_ptr(dev))

@@ -96,12 +96,18 @@ struct Ctx {
     size_t flush_bytes;
 };
 
-template <bool NT, class PR>
-static void launch(const Ctx& c) {
-    auto k = fr::decode_ring_kernel<13, 2, 8, 2, 16, 64, 4, NT, PR>;
+static int g_perm = 0;
+template <bool NT, class PR, bool TILED, bool PERM>
+static void launch_t(const Ctx& c) {
+    auto k = fr::decode_ring_kernel<13, 2, 8, 2, 16, 64, 4, NT, PR, TILED, PERM>;
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
     hipLaunchKernelGGL(k, dim3(c.grid), dim3(1024), c.lds, c.st, c.a);
+}
+template <bool NT, class PR>
+static void launch(const Ctx& c) {
+    if (c.a.tiled) { if (g_perm) launch_t<NT, PR, true, true>(c); else launch_t<NT, PR, true, false>(c); }
+    else { if (g_perm) launch_t<NT, PR, false, true>(c); else launch_t<NT, PR, false, false>(c); }
 }
 
 template <bool NT, class PR>
@@ -225,14 +231,17 @@ static void stamped(const Ctx& c, bool flush, const char* name, unsigned long lo
 
 int main(int argc, char** argv) {
     using namespace fr;
-    const int B = argc > 1 ? atoi(argv[1]) : 64, N = 53215, ns = 199, ne = 29;
+    const int B = argc > 1 ? atoi(argv[1]) : 64, N = argc > 2 ? atoi(argv[2]) : 53215, ns = 199, ne = 29;
+    const int tiled = argc > 3 ? atoi(argv[3]) : 0;
+    const bool quick = argc > 4 && atoi(argv[4]);
+    g_perm = argc > 5 ? atoi(argv[5]) : 0;
     const size_t pb = fr_packed_basis_bytes(N, ns, ne);
     void *packed, *params, *out, *flush;
     unsigned long long* dstamps;
     const size_t flush_bytes = (size_t)512 << 20;
     (void)hipMalloc(&packed, pb);
     (void)hipMalloc(&params, (size_t)B * 235 * 4);
-    (void)hipMalloc(&out, (size_t)B * 3 * N * 4);
+    (void)hipMalloc(&out, (size_t)B * 3 * (N + 64) * 4);
     (void)hipMalloc(&flush, flush_bytes);
     (void)hipMalloc(&dstamps, (size_t)256 * 16 * 16 * 8);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_out), &dstamps, sizeof(dstamps));
@@ -249,7 +258,7 @@ int main(int argc, char** argv) {
     c.a.mu_p = (const float*)(c.a.A + tiles * G * 3 * 64);
     c.a.R_override = nullptr;
     c.a.out = (float*)out;
-    c.a.B = B; c.a.N = N; c.a.ns = ns; c.a.ne = ne; c.a.b0 = 0; c.a.halves = 2; c.a.im_size = 200.f;
+    c.a.B = B; c.a.N = N; c.a.ns = ns; c.a.ne = ne; c.a.b0 = 0; c.a.halves = 2; c.a.im_size = 200.f; c.a.tiled = tiled;
     c.lds = G * KGROUP * 16 * sizeof(float4) + 64 * 12 * sizeof(float) + 64 * 3 * 2 * sizeof(double);
     c.grid = std::min(fr_device_cu_count(), (int)((tiles + 7) / 8));
     c.st = 0;
@@ -258,7 +267,7 @@ int main(int argc, char** argv) {
 
     hipDeviceProp_t prop;
     (void)hipGetDeviceProperties(&prop, 0);
-    printf("{\"device\": \"%s\", \"cus\": %d, \"B\": %d, \"N\": %d, \"items\": %zu, \"mfma_per_item\": 348,\n", prop.gcnArchName, c.grid, B, N, tiles * 2);
+    printf("{\"device\": \"%s\", \"cus\": %d, \"B\": %d, \"N\": %d, \"tiled_output\": %d, \"store_lane_regroup\": %d, \"items\": %zu, \"mfma_per_item\": 348,\n", prop.gcnArchName, c.grid, B, N, tiled, g_perm, tiles * 2);
     printf(" \"mfma_floor_us_at_2.4GHz\": {\"average_6.5_items_per_simd\": %.2f, \"worst_simd_7_items\": %.2f},\n",
            tiles * 2 * 348.0 * 32.0 / 1024.0 / 2.4e3, 7 * 348.0 * 32.0 / 2.4e3);
     printf(" \"timing_us\": {\n");
@@ -268,6 +277,15 @@ int main(int argc, char** argv) {
            name, time_b2b_us<true, PR>(c, 200), time_us<true, PR>(c, false, 41), time_us<true, PR>(c, true, 41),        \
            time_b2b_us<false, PR>(c, 200), time_us<false, PR>(c, false, 41), time_us<false, PR>(c, true, 41),
     ROW("full", AblateProbe<0>) ",");
+    if (quick) {
+        ROW("no_mfma(1)", AblateProbe<1>) ",");
+        ROW("no_stores(32)", AblateProbe<32>) ",");
+        ROW("full_again", AblateProbe<0>) "");
+        printf(" },\n \"stamps\": [\n");
+        stamped<true, 0>(c, true, "product configuration (nt basis), basis from HBM", dstamps, true);
+        printf(" ]}\n");
+        return 0;
+    }
     ROW("no_mfma(1)", AblateProbe<1>) ",");
     ROW("A_from_256_resident_tiles(2)", AblateProbe<2>) ",");
     ROW("no_prologue(4)", AblateProbe<4>) ",");
