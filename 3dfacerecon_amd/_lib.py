@@ -144,6 +144,13 @@ def _bind(L):
     L.fr_decode_q30_workspace_bytes.restype = ctypes.c_size_t
     L.fr_decode_3dmm_q30.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]
     L.fr_decode_3dmm_q30.restype = _i
+    L.fr_decode_render_vertex_pitch.argtypes = [_i]
+    L.fr_decode_render_vertex_pitch.restype = _i
+    L.fr_decode_render_vertex_bytes.argtypes = [_i, _i]
+    L.fr_decode_render_vertex_bytes.restype = ctypes.c_size_t
+    L.fr_decode_render_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _vp,
+                                           ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, _i]
+    L.fr_decode_render_forward.restype = _i
     L.fr_set_option.argtypes = [ctypes.c_char_p, _i]
     L.fr_set_option.restype = _i
     L.fr_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
@@ -165,7 +172,8 @@ EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_r
            "fr_decode_backward_workspace_bytes", "fr_decode_3dmm_backward", "fr_rendering_layer_forward",
            "fr_render_depth_forward_phases", "fr_debug_render_geom", "fr_debug_div3_sweep",
            "fr_render_depth_backward_workspace_bytes", "fr_render_depth_backward_ws", "fr_set_option", "fr_get_option",
-           "fr_decode_q30_image_bytes", "fr_decode_q30_pack", "fr_decode_q30_workspace_bytes", "fr_decode_3dmm_q30"]
+           "fr_decode_q30_image_bytes", "fr_decode_q30_pack", "fr_decode_q30_workspace_bytes", "fr_decode_3dmm_q30",
+           "fr_decode_render_vertex_pitch", "fr_decode_render_vertex_bytes", "fr_decode_render_forward"]
 
 
 def lib():

@@ -176,8 +176,44 @@ int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R
     if ((size_t)B * N == 0) return FR_OK;
     if (!params || !packed_basis || !vertex_proj) return FR_ERR_INVALID_ARG;
     if (((uintptr_t)packed_basis & 15) != 0) return FR_ERR_INVALID_ARG;
-    return fr_launch_decode(params, packed_basis, R_override, B, N, n_shape, n_exp, im_size, vertex_proj,
+    return fr_launch_decode(params, packed_basis, R_override, B, N, n_shape, n_exp, im_size, vertex_proj, N,
                             (hipStream_t)hip_stream);
+}
+
+// ---- fused decode -> render step ---------------------------------------------------------------------------------------
+int fr_decode_render_vertex_pitch(int N) { return N <= 0 ? 0 : (N + 31) & ~31; }
+
+size_t fr_decode_render_vertex_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return (size_t)B * 3 * (size_t)fr_decode_render_vertex_pitch(N) * sizeof(float);
+}
+
+int fr_decode_render_forward(const float* params, const void* packed_basis, const float* R_override, const float* tri,
+                             const float* texture, int B, int N, int n_shape, int n_exp, int ntri, int H, int W,
+                             int tex_batch, float im_size, float* vertex_handoff, size_t vertex_bytes, float* depth,
+                             float* tex_img, float* normal, float* tri_ind, void* workspace, size_t ws_bytes,
+                             void* hip_stream, int phases) {
+    if (phases < 1 || phases > 15) return FR_ERR_INVALID_ARG;
+    if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
+    if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
+    if (B == 0) return FR_OK;
+    const int pitch = fr_decode_render_vertex_pitch(N);
+    if (N > 0 && (!vertex_handoff || vertex_bytes < fr_decode_render_vertex_bytes(B, N) || ((uintptr_t)vertex_handoff & 127)))
+        return FR_ERR_WORKSPACE;
+    if ((phases & 8) && N > 0) {
+        if (!params || !packed_basis) return FR_ERR_INVALID_ARG;
+        if (((uintptr_t)packed_basis & 15) != 0) return FR_ERR_INVALID_ARG;
+        const int rc = fr_launch_decode(params, packed_basis, R_override, B, N, n_shape, n_exp, im_size, vertex_handoff, pitch,
+                                        (hipStream_t)hip_stream);
+        if (rc != FR_OK) return rc;
+    }
+    if (!(phases & 7) || (size_t)H * W == 0) return FR_OK;
+    if (!depth || !tex_img || !normal || !tri_ind) return FR_ERR_INVALID_ARG;
+    if (ntri > 0 && (!tri || (N > 0 && !texture))) return FR_ERR_INVALID_ARG;
+    if (ntri >= (1 << 24)) return FR_ERR_UNSUPPORTED;
+    if (ws_bytes < fr_render_depth_workspace_bytes(B, N, ntri, H, W)) return FR_ERR_WORKSPACE;
+    return fr_launch_render_forward_phases(vertex_handoff, tri, texture, B, N, ntri, H, W, tex_batch, depth, tex_img, normal,
+                                           tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream, phases & 7, pitch);
 }
 
 // ---- opt-in Q30 arithmetic: its own image, its own entry point, caller-owned staging workspace ----------------------------

@@ -116,7 +116,8 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
                              float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream);
 int fr_launch_render_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                                     int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
-                                    float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases);
+                                    float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases,
+                                    long long vpitch = 0);
 int fr_launch_rendering_layer(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
                               int nver, int ntri, int H, int W, int tex_batch, float* net_in, float* depth_img,
                               float* depth, float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream);
@@ -129,7 +130,7 @@ size_t fr_packed_basis_bytes(int N, int n_shape, int n_exp);
 int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
                          void* packed, hipStream_t stream);
 int fr_launch_decode(const float* params, const void* packed, const float* R_override, int B, int N, int n_shape,
-                     int n_exp, float im_size, float* vertex_proj, hipStream_t stream);
+                     int n_exp, float im_size, float* vertex_proj, int pitch, hipStream_t stream);
 size_t fr_packed_q_bytes(int N, int n_shape, int n_exp);
 bool fr_decode_q_supported(int n_shape, int n_exp);
 int fr_launch_pack_q(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,

@@ -140,15 +140,16 @@ __device__ __forceinline__ void mfma_group1(float4 a0, const float* Plg, const i
 // LDS image of the parameters (B operand), per half hf: P[hf][k][j][NBW] floats -- lane l of k-step s reads the NBW
 // consecutive floats at (s*64 + l)*NBW, i.e. one conflict-free ds_read_b32/b64 per k-step.
 // Per-CU prologue shared by the decode kernels: the parameters go to LDS in B-fragment order, the pose to Mt = f.R | t3d.
-template <int NBW, int DEC_BLOCK, int MB = 64>
-__device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem, float* Mt, double* SC, int GS, int GE,
-                                                size_t half_floats, int tid, int nd, int nbatch) {
+template <int NBW, int NT_STAGE, int MB = 64>
+__device__ __forceinline__ void stage_params(const DecodeArgs& a, float* smem, int GS, int GE, size_t half_floats, int tid,
+                                             int nd, int nbatch) {
     // parameters -> LDS in B-fragment order: TPR threads per batch row, each walks the row with stride
     // TPR; loads are unconditional (clamped) and batched so they pipeline; padding slots and absent rows are 0.
     {
-        static_assert(DEC_BLOCK % MB == 0 && DEC_BLOCK >= 3 * MB, "threads per batch row / sincos threads");
-        constexpr int TPR = DEC_BLOCK / MB;  // threads per batch row
+        static_assert(NT_STAGE >= MB, "at least one staging thread per batch row");
+        constexpr int TPR = NT_STAGE / MB;  // threads per batch row (threads beyond TPR * MB have no row)
         const int bb = tid / TPR, sub = tid - bb * TPR;
+        if (bb >= MB) return;
         const bool rowok = bb < nbatch;
         const float* prow = a.params + (size_t)(a.b0 + (rowok ? bb : 0)) * nd + FR_N_POSE;
         const int nbk = bb >> 4;
@@ -181,8 +182,13 @@ __device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem
             }
         }
     }
+}
+template <int NBW, int DEC_BLOCK, int MB = 64>
+__device__ __forceinline__ void decode_prologue(const DecodeArgs& a, float* smem, float* Mt, double* SC, int GS, int GE,
+                                                size_t half_floats, int tid, int nd, int nbatch) {
+    static_assert(DEC_BLOCK % MB == 0 && DEC_BLOCK >= 3 * MB, "threads per batch row / sincos threads");
+    stage_params<NBW, DEC_BLOCK, MB>(a, smem, GS, GE, half_floats, tid, nd, nbatch);
     pose_prologue<MB>(a, Mt, SC, tid, nd, nbatch);
-
 }
 
 template <int NBW, int DEC_WAVES>
@@ -313,8 +319,11 @@ __device__ __forceinline__ void ring_wait(f32x4& slot) {
 // leaves VGPRs free on purpose: the 8-wave form (WPE = 4: <= 128 VGPRs, half the register file) lets the render
 // kernels of the previous batch share the CU with the decode of the next one (pipeline.py, PipelinedPlan).
 // NT: the basis stream is requested with the non-temporal hint (read once per launch by one CU pair of waves).
+// PRIO: static issue priorities for the four waves that share a SIMD (waves w, w+4, w+8, w+12 get 0..3): with equal
+// priorities the sixteen waves of a CU advance in lock-step and reach their epilogues together; ranked, a SIMD tends to run
+// them one after the other, which spreads the epilogues and their stores (decode -1 us dense, -2 us with aligned rows).
 template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64, int WPE = DEC_WAVES / 4, bool NT = false, class PR = NoProbe,
-          bool TILED = false, bool PERM = false>
+          bool PRIO = false>
 __global__ __launch_bounds__(DEC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void decode_ring_kernel(DecodeArgs a) {
     PR pr;
@@ -374,8 +383,19 @@ void decode_ring_kernel(DecodeArgs a) {
         for (int f = 0; f < R; f++) FR_REQ(f, f, t0c)
     }
     pr.template stamp<0>();
+    // per-CU prologue: parameters into LDS (B-fragment order), float64 pose of the pass's columns -> Mt, two barriers.
+    // (Measured and rejected in round 3, A/B in one process: the sincos evaluated by three waves WHILE the other thirteen
+    // stage the parameters and the 3x3 assembly done by one wave behind a single barrier, Mt published through an LDS flag
+    // that every wave checks before its first epilogue: +4.5 us per launch -- thirteen threads per parameter row stage
+    // slower than sixteen, and the assembling wave crawls beside its SIMD's MFMA streams while every first epilogue waits.)
     if constexpr (!(PR::bits & 4)) decode_prologue<NBW, DEC_BLOCK, MB>(a, smem, Mt, SC, GS, GE, half_floats, tid, nd, nbatch);
     pr.template stamp<1>();
+    if constexpr (PRIO) {
+        const int pw = wave >> 2;
+        if (pw == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pw == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pw >= 3) __builtin_amdgcn_s_setprio(3);
+    }
     if (tile0 >= tiles) {
 #pragma unroll
         for (int f = 0; f < R; f++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[f]));
@@ -442,7 +462,7 @@ void decode_ring_kernel(DecodeArgs a) {
         }
         pr.item_mfma_done();
         if ((PR::bits & 32) == 0 || c[0][0][0] + c[1][0][1] + c[2][NBW - 1][2] == 12345.678f)
-            decode_store<NBW, TILED, PERM>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
+            decode_store<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
         pr.item_end();
 #pragma unroll
         for (int cc = 0; cc < 3; cc++)
@@ -502,20 +522,21 @@ static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int cus, size_
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
-template <int GS, int GE, int R, int NBW, int WAVES, int MB = 64, int WPE = WAVES / 4, bool NT = false>
+template <int GS, int GE, int R, int NBW, int WAVES, int MB = 64, int WPE = WAVES / 4, bool NT = false, bool PRIO = false>
 static int launch_decode_ring(const fr::DecodeArgs& a, size_t lds, int cus, size_t tiles, hipStream_t stream) {
     static unsigned char lds_ok[64];
-    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT>), lds_ok) !=
-        hipSuccess)
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT, fr::NoProbe, PRIO>),
+                          lds_ok) != hipSuccess)
         return FR_ERR_LAUNCH;
     const int slots = WAVES / a.halves;
     const int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
-    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT, fr::NoProbe, PRIO>), dim3(grid), dim3(WAVES * 64),
+                       lds, stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
 int fr_launch_decode(const float* params, const void* packed, const float* R_override, int B, int N, int n_shape,
-                     int n_exp, float im_size, float* vertex_proj, hipStream_t stream) {
+                     int n_exp, float im_size, float* vertex_proj, int pitch, hipStream_t stream) {
     using namespace fr;
     if (B == 0 || N == 0) return FR_OK;
     size_t tiles = (size_t)tiles_of(N);
@@ -530,7 +551,7 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
     a.out = vertex_proj;
     a.B = B; a.N = N; a.ns = n_shape; a.ne = n_exp;
     a.im_size = im_size;
-    a.tiled = 0;
+    a.pitch = pitch;
     const int cus = fr_device_cu_count();
     const bool loop_env = opt(OPT_DECODE_IMPL) == 1;
     const bool wide_off = opt(OPT_DECODE_WIDE) == 0;
@@ -565,7 +586,7 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
             // the basis stream carries the non-temporal hint: it is read once per launch, and keeping its 153 MB out of
             // the way leaves the L2 / Infinity Cache to the vertices and hit records the render kernels re-read (measured
             // in the pipeline: decode +2 us, emit -1.5 us, resolve -5 us per 64-face step)
-            rc = launch_decode_ring<13, 2, 8, 2, 16, 64, 4, true>(a, lds, cus, tiles, stream);
+            rc = launch_decode_ring<13, 2, 8, 2, 16, 64, 4, true, true>(a, lds, cus, tiles, stream);
         else
             rc = nbw == 1   ? launch_decode_nbw<1, 16>(a, lds, cus, tiles, stream)
                  : nbw == 2 ? launch_decode_nbw<2, 16>(a, lds, cus, tiles, stream)

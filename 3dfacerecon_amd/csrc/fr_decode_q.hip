@@ -591,7 +591,7 @@ int fr_launch_decode_q(const float* params, const void* qimage, const float* R_o
     a.d.B = B; a.d.N = N; a.d.ns = n_shape; a.d.ne = n_exp;
     a.d.halves = 1;
     a.d.im_size = im_size;
-    a.d.tiled = 0;
+    a.d.pitch = N;
     const size_t lds = q_stage_bytes(a.qs.S);
     if (lds > 160 * 1024) return FR_ERR_UNSUPPORTED;
     if (!workspace || ws_bytes < lds || ((uintptr_t)workspace & 15)) return FR_ERR_WORKSPACE;

@@ -22,17 +22,10 @@ struct DecodeArgs {
     int b0;                   // first batch column of this pass
     int halves;               // column-block groups per tile: a work item is (tile, half)
     float im_size;
-    int tiled;                // 0: out is the dense [B,3,N] tensor of the op surface; 1: the plan's private hand-off layout
-                              // [ceil(N/32)][3][B][32] (vertex_tiled_offset): every wave store is an aligned 64-byte half of
-                              // a 128-byte line whose other half the neighbouring tile's wave writes, 24 KiB contiguous per
-                              // 32-vertex block at B = 64 -- instead of 192 unaligned 64-byte pieces 213 KB apart
-                              // (selects the TILED instantiation of the kernel; not read on the device)
+    int pitch;                // floats between consecutive coordinate rows of `out` (>= N; N for the dense [B,3,N] tensor of
+                              // the op surface; the fused decode -> render entry point pads it to a multiple of 32 so that
+                              // every 16-vertex tile piece is an aligned 64-byte half of a 128-byte line)
 };
-
-// element (b, c, p) of the tiled hand-off layout, in floats
-__host__ __device__ inline size_t vertex_tiled_offset(int B, int b, int c, int p) {
-    return (((size_t)(p >> 5) * 3 + c) * B + b) * 32 + (p & 31);
-}
 
 // rotation in float64 exactly as network.py:276-290: R = (R_pitch . R_yaw) . R_roll, 3-term dots, no FMA.
 __device__ __forceinline__ void mat3_mul(const double* A, const double* Bm, double* C) {
@@ -117,26 +110,20 @@ __device__ __forceinline__ void pose_prologue(const DecodeArgs& a, float* Mt, do
 
 }
 
-// Fused epilogue of one work item: 3x3 (f.R) transform, +t3d, y flip, store.
-// The MFMA leaves lane l with batch column b = l & 15 and vertex group g = l >> 4 (vertices 4g .. 4g+3 of the tile), so the
-// 64 contiguous bytes a tile contributes to one output row sit in the four lanes g = 0..3 that are 16 lanes APART, and every
-// group of four adjacent lanes addresses four different rows: a store instruction is 64 separate 16-byte pieces to the
-// memory pipeline.  PERM regroups the values first (ds_bpermute: the LDS crossbar, no LDS memory) so that lane
-// l' = 4 b + g -- four ADJACENT lanes then hold one row's 64 bytes and a store instruction is 16 pieces of 64 bytes.
-// TILED: the plan's private hand-off layout (vertex_tiled_offset) instead of the dense [B,3,N] tensor.
-template <int NBW, bool TILED = false, bool PERM = false>
+// Fused epilogue of one work item: 3x3 (f.R) transform, +t3d, y flip, store to [B,3,pitch] rows.
+// (Measured and not adopted, profiles/round3_probes: regrouping the lanes with ds_bpermute so that four ADJACENT lanes hold
+// one row's 64 contiguous bytes: no change; a tile-blocked hand-off layout [N/32][3][B][32]: -3 us, [N/16][3][B][16] with
+// lane-linear 1 KiB stores: -5 us for the decode, at the price of half-used cache lines in the emit kernel's gathers.)
+template <int NBW>
 __device__ __forceinline__ void decode_store(const DecodeArgs& a, const f32x4 (&s0)[NBW], const f32x4 (&s1)[NBW],
                                              const f32x4 (&s2)[NBW], const float* Mt, int tile, int hf, int lane,
                                              int nbatch, int N) {
-    const int lb = PERM ? (lane >> 2) : (lane & 15);   // batch column (of 16) this lane STORES
-    const int lg = PERM ? (lane & 3) : (lane >> 4);    // vertex group this lane STORES
-    const int p0v = tile * TILE_V + 4 * lg;            // first of the four vertices this lane stores
-    const int src4 = PERM ? ((((lane & 3) << 4) | (lane >> 2)) << 2) : 0;  // byte address of the lane whose values it takes
+    const int p0v = tile * TILE_V + 4 * (lane >> 4);  // first of this lane's 4 vertices
 #pragma unroll
     for (int nb = 0; nb < NBW; nb++) {
-        const int bc = 16 * (hf * NBW + nb);
-        if (!PERM && bc + lb >= nbatch) continue;
-        const float* m = Mt + (bc + (lane & 15)) * 12;   // the column whose values this lane COMPUTES (absent rows: zeros)
+        const int bb = 16 * (hf * NBW + nb) + (lane & 15);
+        if (bb >= nbatch) continue;
+        const float* m = Mt + bb * 12;
         f32x4 px, py, pz;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -148,38 +135,20 @@ __device__ __forceinline__ void decode_store(const DecodeArgs& a, const f32x4 (&
             py[r] = (a.im_size - qy) - 1.0f;  // network.py:168
             pz[r] = qz;
         }
-        if constexpr (PERM) {
+        float* ox = a.out + ((size_t)(a.b0 + bb) * 3) * a.pitch + p0v;
+        float* oy = ox + a.pitch;
+        float* oz = oy + a.pitch;
+        if (p0v + 3 < N) {
+            *reinterpret_cast<f32x4u*>(ox) = px;
+            *reinterpret_cast<f32x4u*>(oy) = py;
+            *reinterpret_cast<f32x4u*>(oz) = pz;
+        } else {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                px[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(px[r])));
-                py[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(py[r])));
-                pz[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(pz[r])));
-            }
-            if (bc + lb >= nbatch) continue;
-        }
-        const int bb = bc + lb;
-        if constexpr (TILED) {  // (p0v is a multiple of 4: the four vertices stay inside one 32-vertex block)
-            float* o = a.out + vertex_tiled_offset(a.B, a.b0 + bb, 0, p0v);
-            const size_t cs = (size_t)a.B * 32;
-            *reinterpret_cast<f32x4*>(o) = px;
-            *reinterpret_cast<f32x4*>(o + cs) = py;
-            *reinterpret_cast<f32x4*>(o + 2 * cs) = pz;
-        } else {
-            float* ox = a.out + ((size_t)(a.b0 + bb) * 3) * N + p0v;
-            float* oy = ox + N;
-            float* oz = oy + N;
-            if (p0v + 3 < N) {
-                *reinterpret_cast<f32x4u*>(ox) = px;
-                *reinterpret_cast<f32x4u*>(oy) = py;
-                *reinterpret_cast<f32x4u*>(oz) = pz;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (p0v + r < N) {
-                        ox[r] = px[r];
-                        oy[r] = py[r];
-                        oz[r] = pz[r];
-                    }
+                if (p0v + r < N) {
+                    ox[r] = px[r];
+                    oy[r] = py[r];
+                    oz[r] = pz[r];
                 }
             }
         }

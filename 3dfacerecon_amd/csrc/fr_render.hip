@@ -34,7 +34,8 @@
 namespace fr {
 
 struct RenderArgs {
-    const float* vertex;   // [B,3,nver]
+    const float* vertex;   // [B,3,vpitch] rows (vpitch == nver: the dense tensor of the op surface)
+    long long vpitch;      // floats between consecutive coordinate rows of `vertex`
     const float* tri;      // [3,ntri]
     const float* texture;  // [tex_batch,3,nver]
     float* depth;          // [B,H,W,1]
@@ -331,7 +332,7 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
                 for (int k = 0; k < 4; k++)
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        const float* vc = vx + (size_t)c * nver;
+                        const float* vc = vx + (size_t)c * a.vpitch;
                         const float* tc = tex + (size_t)c * nver;
 #pragma unroll
                         for (int v = 0; v < 3; v++) {
@@ -400,9 +401,9 @@ __global__ __launch_bounds__(BLOCK) void render_strip_kernel(RenderArgs a) {
     const unsigned long long KBG = bg_key();
     for (int i = tid; i < npix; i += BLOCK) keys[i] = KBG;
     __syncthreads();
-    const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.nver;
-    const float* __restrict__ vy = vx + a.nver;
-    const float* __restrict__ vz = vy + a.nver;
+    const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.vpitch;
+    const float* __restrict__ vy = vx + a.vpitch;
+    const float* __restrict__ vz = vy + a.vpitch;
     for (int t = tid; t < a.ntri; t += BLOCK)
         raster_triangle_into_strip(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, a.W, r0, r1, keys);
     __syncthreads();
@@ -491,9 +492,9 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     __syncthreads();
 
     const int nver = a.nver, ntri = a.ntri;
-    const float* __restrict__ vx = a.vertex + (size_t)b * 3 * nver;
-    const float* __restrict__ vy = vx + nver;
-    const float* __restrict__ vz = vy + nver;
+    const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.vpitch;
+    const float* __restrict__ vy = vx + a.vpitch;
+    const float* __restrict__ vz = vy + a.vpitch;
 
     // ---------------- phase A: pre-validated ids, gathers, bbox reject ----------------
     {
@@ -794,9 +795,9 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     uint32_t* slotlist = wtot + 64;                                             // [SLOT_CAP] record slot of list entry j
     const unsigned long long KBG = bg_key();
     for (int i = tid; i < npix; i += BLOCK) keys[i] = KBG;
-    const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.nver;
-    const float* __restrict__ vy = vx + a.nver;
-    const float* __restrict__ vz = vy + a.nver;
+    const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.vpitch;
+    const float* __restrict__ vy = vx + a.vpitch;
+    const float* __restrict__ vz = vy + a.vpitch;
     // where the winners' normals go: the strip's slice of the normal plane, or (fused) channels 4..6 of the 7-channel
     // CoarseNet input, post-processed
     constexpr int NSTRIDE = FUSED ? 7 : 3;
@@ -1357,7 +1358,7 @@ static int launch_resolve(const fr::RenderArgs& a, long long nbins, size_t lds, 
 static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
                               int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
                               const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
-                              hipStream_t stream, int phases = 7);
+                              hipStream_t stream, int phases = 7, long long vpitch = 0);
 
 int fr_launch_render_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                              int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
@@ -1369,9 +1370,10 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
 // the forward op phase by phase: 4 = pack the triangle list into the workspace, 1 = emit, 2 = resolve (7 = the whole op)
 int fr_launch_render_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                                     int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
-                                    float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases) {
+                                    float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases,
+                                    long long vpitch) {
     return launch_render_impl(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr,
-                              nullptr, nullptr, workspace, ws_bytes, stream, phases);
+                              nullptr, nullptr, workspace, ws_bytes, stream, phases, vpitch);
 }
 
 int fr_launch_rendering_layer(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
@@ -1384,7 +1386,7 @@ int fr_launch_rendering_layer(const float* vertex, const float* tri, const float
 static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
                               int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
                               const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
-                              hipStream_t stream, int phases) {
+                              hipStream_t stream, int phases, long long vpitch) {
     using namespace fr;
     const bool fused = net_in != nullptr;
     constexpr int BLOCK = 1024;
@@ -1396,6 +1398,7 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
 
     RenderArgs a;
     a.vertex = vertex; a.tri = tri; a.texture = texture;
+    a.vpitch = vpitch > 0 ? vpitch : nver;
     a.depth = depth; a.tex_img = tex_img; a.normal = normal; a.tri_ind = tri_ind;
     a.B = B; a.nver = nver; a.ntri = ntri; a.H = H; a.W = W;
     a.rows = g.rows; a.strips = g.strips;

@@ -2,11 +2,14 @@
 
 `FaceRecNet.vertices_transform` + `rendering_layer.ops.render_depth` allocate their outputs per call, like the
 reference op does (render_depth_op.cc:442-445).  A serving / training loop that runs the same shapes every
-iteration should not pay that: a `DecodeRenderPlan` owns the vertex buffer and the four output planes once
-(HBM is 288 GB; one 64-face plan is 123 MB), keeps the ctypes argument lists prebuilt, launches both kernels on
-torch's current HIP stream, and can be captured into a hipGraph (`capture()` / `replay()`), so one batch costs
-one graph launch instead of a Python call chain.  Outputs are views of the plan's buffers: they are overwritten
-by the next `step()`.  Forward only (no autograd); use rendering_layer.ops.render_depth when gradients are needed.
+iteration should not pay that: a `DecodeRenderPlan` owns the vertex hand-off buffer and the four output planes once
+(HBM is 288 GB; one 64-face plan is 123 MB), keeps the ctypes argument list prebuilt, and runs the fused
+decode -> render entry point (fr_decode_render_forward: ONE C call, three kernel launches on torch's current HIP
+stream); it can be captured into a hipGraph (`capture()` / `replay()`).  The projected vertices are handed from the
+decode to the rasteriser in the library's pitched row layout (rows padded to 128-byte multiples, so every decode
+store is an aligned half line); `plan.vertex_proj` is the strided [B,3,N] VIEW of that buffer -- same values, same
+indexing, not contiguous.  Outputs are views of the plan's buffers: they are overwritten by the next `step()`.
+Forward only (no autograd); use rendering_layer.ops.render_depth when gradients are needed.
 """
 import ctypes
 import importlib.util
@@ -35,7 +38,7 @@ class DecodeRenderPlan:
         tensor, default net.vertex_code (the PNCC colour code, reference network.py:116)."""
         h = _host()
         self._h = h
-        self._L = h.lib()
+        self._L = L = h.lib()
         self.net = net
         self.device = net.device
         self.B = int(batch)
@@ -45,7 +48,6 @@ class DecodeRenderPlan:
         self.T = int(net.tri.shape[1])
         f32 = dict(dtype=torch.float32, device=self.device)
         self.params = torch.zeros((self.B, net.ndim), **f32)
-        self.vertex_proj = torch.empty((self.B, 3, self.N), **f32)
         self.depth = torch.empty((self.B, self.H, self.W, 1), **f32)
         self.texture_image = torch.empty((self.B, self.H, self.W, 3), **f32)
         self.normal = torch.empty((self.B, self.H, self.W, 3), **f32)
@@ -55,70 +57,82 @@ class DecodeRenderPlan:
         self.tex_batch = 1 if self.texture.dim() == 2 else int(self.texture.shape[0])
         if self.tex_batch not in (1, self.B) or self.texture.shape[-2] != 3 or self.texture.shape[-1] != self.N:
             raise ValueError("texture must be (3,N), (1,3,N) or (B,3,N)")
-        ws_bytes = self._L.fr_render_depth_workspace_bytes(self.B, self.N, self.T, self.H, self.W)
+        ws_bytes = L.fr_render_depth_workspace_bytes(self.B, self.N, self.T, self.H, self.W)
         self._ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=self.device)
         self._ws_bytes = ws_bytes
         p = h.ptr
-        # the decode entry point is fixed when the plan is built: the f32 chain, or -- when the opt-in Q30 arithmetic is
-        # selected at that moment -- fr_decode_3dmm_q30 with a staging workspace the PLAN owns (nothing is allocated at
-        # launch time, so the plan can be captured on any stream)
+        # The decode arithmetic is fixed when the plan is built: the f32 chain through the fused entry point, or -- when the
+        # opt-in Q30 arithmetic is selected at that moment -- fr_decode_3dmm_q30 (dense rows) with a staging workspace the
+        # PLAN owns, followed by the render phases.  Nothing is allocated at launch time either way, so the plan can be
+        # captured on any stream.
         basis = net._basis
         self.q30 = basis.use_q30()
+        self.pitch = self.N if self.q30 else int(L.fr_decode_render_vertex_pitch(self.N))
+        self._vertex = torch.empty((self.B, 3, self.pitch), **f32)     # (torch allocations are >= 256-byte aligned)
+        self._vertex_bytes = self._vertex.numel() * 4
+        self.vertex_proj = self._vertex[:, :, :self.N]                   # [B,3,N]; a strided view when pitch > N
         if self.q30:
             self._q_ws = torch.empty((basis.q30_ws_bytes,), dtype=torch.uint8, device=self.device)
-            self._dec_fn = self._L.fr_decode_3dmm_q30
-            self._dec_args = (p(self.params), p(basis.qimage()), None, self.B, self.N, net.ndim_shape, net.ndim_exp,
-                              ctypes.c_float(float(net.im_size)), p(self.vertex_proj), p(self._q_ws), basis.q30_ws_bytes)
+            self._q_args = (p(self.params), p(basis.qimage()), None, self.B, self.N, net.ndim_shape, net.ndim_exp,
+                            ctypes.c_float(float(net.im_size)), p(self._vertex), p(self._q_ws), basis.q30_ws_bytes)
+            self._ren_args = (p(self._vertex), p(net.tri), p(self.texture), self.B, self.N, self.T, self.H, self.W, 3,
+                              self.tex_batch, p(self.depth), p(self.texture_image), p(self.normal), p(self.tri_ind),
+                              p(self._ws), ws_bytes)
         else:
-            self._dec_fn = self._L.fr_decode_3dmm
-            self._dec_args = (p(self.params), p(basis.image), None, self.B, self.N, net.ndim_shape, net.ndim_exp,
-                              ctypes.c_float(float(net.im_size)), p(self.vertex_proj))
-        self._ren_args = (p(self.vertex_proj), p(net.tri), p(self.texture), self.B, self.N, self.T, self.H, self.W, 3,
-                          self.tex_batch, p(self.depth), p(self.texture_image), p(self.normal), p(self.tri_ind),
-                          p(self._ws), ws_bytes)
+            self._fused_args = (p(self.params), p(basis.image), None, p(net.tri), p(self.texture), self.B, self.N,
+                                net.ndim_shape, net.ndim_exp, self.T, self.H, self.W, self.tex_batch,
+                                ctypes.c_float(float(net.im_size)), p(self._vertex), self._vertex_bytes, p(self.depth),
+                                p(self.texture_image), p(self.normal), p(self.tri_ind), p(self._ws), ws_bytes)
         self._graph = None
         # the triangle list is a constant of the model (reference network.py:178): convert + range-check it ONCE into the
-        # workspace's table; every step then runs the emit and resolve phases only
+        # workspace's table; every step then runs the decode, emit and resolve phases only
         self._tri_packed = False
         self.pack_tri()
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _run(self, phases):
+        """Phase bits of fr_decode_render_forward: 8 = decode, 4 = pack the triangle list, 1 = emit, 2 = resolve."""
+        if self.q30:   # frozen experiment: its own decode entry point, then the render phases on dense rows
+            if phases & 8:
+                rc = self._L.fr_decode_3dmm_q30(*self._q_args, self._stream())
+                if rc:
+                    self._h.check(rc, "fr_decode_3dmm_q30")
+            if phases & 7:
+                rc = self._L.fr_render_depth_forward_phases(*self._ren_args, self._stream(), phases & 7)
+                if rc:
+                    self._h.check(rc, "fr_render_depth_forward_phases")
+            return
+        rc = self._L.fr_decode_render_forward(*self._fused_args, self._stream(), phases)
+        if rc:
+            self._h.check(rc, "fr_decode_render_forward")
 
     def pack_tri(self):
         """(Re)builds the pre-validated triangle table in the workspace; call again after changing net.tri in place."""
         with torch.cuda.device(self.device):
-            rc = self._L.fr_render_depth_forward_phases(*self._ren_args, self._stream(), 4)
-        if rc:
-            self._h.check(rc, "fr_render_depth_forward_phases(pack)")
+            self._run(4)
         self._tri_packed = True
 
     # -- eager launches on the current stream ---------------------------------------------------------------
-    def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-
     def decode(self):
-        rc = self._dec_fn(*self._dec_args, self._stream())
-        if rc:
-            self._h.check(rc, "fr_decode_3dmm_q30" if self.q30 else "fr_decode_3dmm")
+        self._run(8)
 
     def render(self):
-        rc = self._L.fr_render_depth_forward_phases(*self._ren_args, self._stream(), 3)
-        if rc:
-            self._h.check(rc, "fr_render_depth_forward_phases")
+        self._run(3)
 
     def render_phase(self, phases):
         """phases = 1 launches only raster_emit_kernel, 2 only resolve_write_kernel, 4 only pack_tri_kernel."""
-        rc = self._L.fr_render_depth_forward_phases(*self._ren_args, self._stream(), int(phases))
-        if rc:
-            self._h.check(rc, "fr_render_depth_forward_phases")
+        self._run(int(phases) & 7)
 
     def outputs(self):
         return self.depth, self.texture_image, self.normal, self.tri_ind
 
     def step(self, params=None):
-        """decode + render of one batch.  `params` (B,d) is copied into the plan's buffer when given."""
+        """decode + render of one batch (one C call).  `params` (B,d) is copied into the plan's buffer when given."""
         if params is not None:
             self.params.copy_(params.reshape(self.B, -1), non_blocking=True)
-        self.decode()
-        self.render()
+        self._run(11)
         return self.outputs()
 
     # -- hipGraph ------------------------------------------------------------------------------------------------
@@ -129,8 +143,7 @@ class DecodeRenderPlan:
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self.decode()
-                self.render()
+                self._run(11)
         self._graph = g
         return g
 

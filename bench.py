@@ -156,7 +156,7 @@ def parity_gate(plan, net, assets, params_np, H, W, n_faces):
     n = min(int(n_faces), plan.B)
     plan.step()
     torch.cuda.synchronize(plan.device)
-    V = plan.vertex_proj[:n].cpu().numpy()
+    V = plan.vertex_proj[:n].contiguous().cpu().numpy()   # (the plan hands the vertices over in pitched rows: a strided view)
     got = [t[:n].cpu().numpy() for t in plan.outputs()]
     want = O.render_depth(V, assets["tri"], assets["vertex"][None], H, W)
     bad_planes = 0

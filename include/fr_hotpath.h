@@ -144,6 +144,24 @@ int fr_decode_pack_basis(const float* mu, const float* pc_shape, const float* pc
 int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R_override, int B, int N,
                    int n_shape, int n_exp, float im_size, float* vertex_proj, void* hip_stream);
 
+/* ---- fused decode -> render step (reference hand-off nets/network.py:140-171 -> :174-182) ---------
+ * One call launches fr_decode_3dmm and then fr_render_depth_forward_phases on its result.  The projected vertices never
+ * take the op surface's dense [B,3,N] form: they are handed from the decode to the rasteriser in a buffer the CALLER owns
+ * but whose layout is the library's -- [B,3,pitch] rows with pitch = fr_decode_render_vertex_pitch(N) (N rounded up to a
+ * multiple of 32 floats), fr_decode_render_vertex_bytes(B, N) bytes, 128-byte aligned: every 16-vertex piece a decode wave
+ * stores is then an aligned half of a 128-byte line (N = 53,215 is odd: in the dense tensor every row starts at another
+ * 4-byte phase and every 64-byte piece straddles two lines; measured -2.7 us per 64-face decode).  Element (b, c, p) sits at
+ * (b * 3 + c) * pitch + p, so a strided view of the buffer IS the [B,3,N] tensor (the pad floats are never written or read).
+ *   phases: bit 8 = decode, bit 4 = pack the triangle list, bit 1 = emit, bit 2 = resolve (15 = everything; a caller whose
+ *   triangle list is a model constant runs 4 once and 11 per batch).  Results are bit-identical to the two separate calls. */
+int fr_decode_render_vertex_pitch(int N);
+size_t fr_decode_render_vertex_bytes(int B, int N);
+int fr_decode_render_forward(const float* params, const void* packed_basis, const float* R_override, const float* tri,
+                             const float* texture, int B, int N, int n_shape, int n_exp, int ntri, int H, int W,
+                             int tex_batch, float im_size, float* vertex_handoff, size_t vertex_bytes, float* depth,
+                             float* tex_img, float* normal, float* tri_ind, void* workspace, size_t ws_bytes,
+                             void* hip_stream, int phases);
+
 /* Opt-in second definition of the same decode (frozen experiment; nothing of it is built, allocated or
  * launched unless these entry points are called):
  *   Q30: v = fl32(mu + S + E) with S + E an EXACT fixed-point dot product of the operands quantised to 31 bits against

@@ -167,6 +167,9 @@ def test_plan_matches_operator_surface(full_assets, synth):
     got = [o.clone() for o in plan.step(P)]
     for g, w in zip(got, want):
         assert torch.equal(g, w)
+    # the fused entry point hands the vertices over in pitched rows: plan.vertex_proj is the strided [B,3,N] view of them
+    assert plan.pitch % 32 == 0 and plan.pitch >= plan.N and tuple(plan.vertex_proj.shape) == (3, 3, plan.N)
+    assert torch.equal(plan.vertex_proj, V)
     got2 = [o.clone() for o in plan.replay(P)]
     for g, w in zip(got2, want):
         assert torch.equal(g, w)
@@ -186,7 +189,7 @@ def test_plan_route_full_batch64_every_face_against_the_oracle(oracle, full_asse
     plan = pipe.DecodeRenderPlan(net, B, 200, 200)
     got = [o.clone() for o in plan.step(torch.as_tensor(P, device="cuda:0"))]
     torch.cuda.synchronize()
-    V = plan.vertex_proj.cpu().numpy()
+    V = plan.vertex_proj.contiguous().cpu().numpy()
     want = oracle.render_depth(V, A["tri"], A["vertex"][None], 200, 200)
     for b in range(B):
         assert_render_equal(tuple(g[b:b + 1].cpu().numpy() for g in got), tuple(w[b:b + 1] for w in want), "plan face %d" % b)

@@ -96,18 +96,18 @@ struct Ctx {
     size_t flush_bytes;
 };
 
-static int g_perm = 0;
-template <bool NT, class PR, bool TILED, bool PERM>
+static int g_prio = 1;
+template <bool NT, class PR, bool PRIO>
 static void launch_t(const Ctx& c) {
-    auto k = fr::decode_ring_kernel<13, 2, 8, 2, 16, 64, 4, NT, PR, TILED, PERM>;
+    auto k = fr::decode_ring_kernel<13, 2, 8, 2, 16, 64, 4, NT, PR, PRIO>;
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
     hipLaunchKernelGGL(k, dim3(c.grid), dim3(1024), c.lds, c.st, c.a);
 }
 template <bool NT, class PR>
 static void launch(const Ctx& c) {
-    if (c.a.tiled) { if (g_perm) launch_t<NT, PR, true, true>(c); else launch_t<NT, PR, true, false>(c); }
-    else { if (g_perm) launch_t<NT, PR, false, true>(c); else launch_t<NT, PR, false, false>(c); }
+    if (g_prio) launch_t<NT, PR, true>(c);
+    else launch_t<NT, PR, false>(c);
 }
 
 template <bool NT, class PR>
@@ -231,10 +231,11 @@ static void stamped(const Ctx& c, bool flush, const char* name, unsigned long lo
 
 int main(int argc, char** argv) {
     using namespace fr;
+    // decode_probe [B] [N] [pitched rows 0|1] [quick 0|1] [wave priorities 0|1]
     const int B = argc > 1 ? atoi(argv[1]) : 64, N = argc > 2 ? atoi(argv[2]) : 53215, ns = 199, ne = 29;
-    const int tiled = argc > 3 ? atoi(argv[3]) : 0;
+    const int pitched = argc > 3 ? atoi(argv[3]) : 1;
     const bool quick = argc > 4 && atoi(argv[4]);
-    g_perm = argc > 5 ? atoi(argv[5]) : 0;
+    g_prio = argc > 5 ? atoi(argv[5]) : 1;
     const size_t pb = fr_packed_basis_bytes(N, ns, ne);
     void *packed, *params, *out, *flush;
     unsigned long long* dstamps;
@@ -258,16 +259,32 @@ int main(int argc, char** argv) {
     c.a.mu_p = (const float*)(c.a.A + tiles * G * 3 * 64);
     c.a.R_override = nullptr;
     c.a.out = (float*)out;
-    c.a.B = B; c.a.N = N; c.a.ns = ns; c.a.ne = ne; c.a.b0 = 0; c.a.halves = 2; c.a.im_size = 200.f; c.a.tiled = tiled;
+    c.a.B = B; c.a.N = N; c.a.ns = ns; c.a.ne = ne; c.a.b0 = 0; c.a.halves = 2; c.a.im_size = 200.f; c.a.pitch = pitched ? (N + 31) & ~31 : N;
     c.lds = G * KGROUP * 16 * sizeof(float4) + 64 * 12 * sizeof(float) + 64 * 3 * 2 * sizeof(double);
     c.grid = std::min(fr_device_cu_count(), (int)((tiles + 7) / 8));
     c.st = 0;
     c.flush = flush;
     c.flush_bytes = flush_bytes;
 
+    if (argc > 6 && atoi(argv[6])) {   // interleaved A/B of (pitch, prio, late pose) in one process: median of 9 rounds each
+        printf("{\"ab_after_512MiB_flush_us\": {\n");
+        double res[4][9];
+        for (int r = 0; r < 9; r++)
+            for (int v = 0; v < 4; v++) {
+                c.a.pitch = (v & 1) ? (N + 31) & ~31 : N; g_prio = (v >> 1) & 1;
+                res[v][r] = time_us<true, AblateProbe<0>>(c, true, 7);
+            }
+        for (int v = 0; v < 4; v++) {
+            std::sort(res[v], res[v] + 9);
+            printf("  \"pitched=%d prio=%d\": {\"median\": %.2f, \"min\": %.2f, \"max\": %.2f}%s\n", v & 1, (v >> 1) & 1,
+                   res[v][4], res[v][0], res[v][8], v == 3 ? "" : ",");
+        }
+        printf("}}\n");
+        return 0;
+    }
     hipDeviceProp_t prop;
     (void)hipGetDeviceProperties(&prop, 0);
-    printf("{\"device\": \"%s\", \"cus\": %d, \"B\": %d, \"N\": %d, \"tiled_output\": %d, \"store_lane_regroup\": %d, \"items\": %zu, \"mfma_per_item\": 348,\n", prop.gcnArchName, c.grid, B, N, tiled, g_perm, tiles * 2);
+    printf("{\"device\": \"%s\", \"cus\": %d, \"B\": %d, \"N\": %d, \"row_pitch\": %d, \"wave_priorities\": %d, \"items\": %zu, \"mfma_per_item\": 348,\n", prop.gcnArchName, c.grid, B, N, c.a.pitch, g_prio, tiles * 2);
     printf(" \"mfma_floor_us_at_2.4GHz\": {\"average_6.5_items_per_simd\": %.2f, \"worst_simd_7_items\": %.2f},\n",
            tiles * 2 * 348.0 * 32.0 / 1024.0 / 2.4e3, 7 * 348.0 * 32.0 / 2.4e3);
     printf(" \"timing_us\": {\n");
