@@ -471,14 +471,25 @@ __device__ __forceinline__ float div3(float x) {
 // and survivors are compacted into an LDS queue.  Phase B runs the expensive part (depth, fp64 barycentric test,
 // normal, record emission) on DENSE waves -- about half as many wave-instructions -- and parks the records in LDS.
 // Phase C counting-sorts them by strip and writes them out.
+// Development hooks of the emit kernel (tools/emit_probe.hip supplies a stamping policy; the product instantiates NoEmitProbe,
+// whose hooks are empty inlines).
+struct NoEmitProbe {
+    __device__ __forceinline__ void begin() {}
+    template <int ID> __device__ __forceinline__ void stamp() {}
+    __device__ __forceinline__ void finish(int) {}
+};
 constexpr int EMIT_BLOCK = 256;
 constexpr int TPT = 2;                 // triangles per thread in phase A
 constexpr int EMIT_ACTIVE = SEG / TPT; // threads that own triangles in phase A (252 of 256)
 
+template <class PR = NoEmitProbe>
 __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
+    PR pr;
+    pr.begin();
     __shared__ uint32_t cnt[OFF_STRIDE];  // per-bucket record count; turned into the bucket's start offset in phase C
-    __shared__ unsigned long long qn2;  // survivors queued: low word = single-pixel ones (from slot 0 up), high word =
-                                        // multi-pixel ones (from slot SEG-1 down)
+    __shared__ uint32_t wq[EMIT_BLOCK / 64];  // per wave: survivors queued in the wave's own region of the queue -- low half
+                                              // = single-pixel ones (from the region's first slot up), high half = multi-pixel
+                                              // ones (from its last slot down)
     __shared__ float4 qa[SEG];   // phase A->B: x1 y1 x2 y2          phase B->C: the record
     __shared__ float4 qb[SEG];   // phase A->B: x3 y3 z1 z2          phase B->C: the record's normal
     __shared__ uint2 qd[SEG];    // .x: z3 (raw bits) in A->B, then bucket << 16 | pos (~0 = none) in B->C; .y: local index
@@ -487,9 +498,10 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     const int b = a.nseg_magic ? (int)__umulhi((uint32_t)lid, a.nseg_magic) : lid / a.nseg;  // lid / nseg
     const int seg = lid - b * a.nseg;
     const int S = a.strips;
+    // (no barrier here: the bucket counters are first touched in phase B, behind the barrier that ends phase A, and the
+    // survivor queue is not allocated with an atomic on a shared counter any more -- every wave fills its OWN region)
     if (tid < 2 * S) cnt[tid] = 0;
-    if (tid == 0) qn2 = 0ull;
-    __syncthreads();
+    pr.template stamp<0>();
 
     const int nver = a.nver, ntri = a.ntri;
     const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.vpitch;
@@ -558,40 +570,54 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
                 a.tritex_ws[seg * SEG + u * EMIT_ACTIVE + tid] = make_float4(tm[0], tm[1], tm[2], 0.0f);
             }
         }
-        // Survivors of both triangles are compacted with ONE LDS atomic per wave, into a two-ended queue: bboxes holding a
-        // single pixel centre (~78 % on the BFM-scale mesh) fill it from the front, the others from the back.  Phase B's
-        // waves are then (nearly) homogeneous: the pixel loop of a wave runs as long as its LONGEST lane, and mixing one
-        // 2- or 4-pixel triangle into a wave of 1-pixel ones doubles that wave's fp64 work.
-        static_assert(TPT == 2, "compaction below is written for two triangles per thread");
+        pr.template stamp<1>();   // gathers back, bbox + pre-cull done
+        // Survivors of both triangles are compacted into a two-ended queue: bboxes holding a single pixel centre (~78 % on
+        // the BFM-scale mesh) fill it from the front, the others from the back.  Phase B's waves are then (nearly)
+        // homogeneous: the pixel loop of a wave runs as long as its LONGEST lane, and mixing one 2- or 4-pixel triangle into
+        // a wave of 1-pixel ones doubles that wave's fp64 work.  Every wave owns the region [128 w, 128 w + its triangle
+        // count) of the queue -- it can hold all of the wave's triangles -- so a slot is the wave-local rank: no atomic, no
+        // shared counter that would have to be zeroed behind a barrier of its own.
+        static_assert(TPT == 2 && EMIT_ACTIVE <= EMIT_BLOCK && SEG <= 2 * EMIT_BLOCK, "compaction below: two triangles per thread");
         const unsigned long long ms0 = __ballot(surv[0] && single[0]), ms1 = __ballot(surv[1] && single[1]);
         const unsigned long long mm0 = __ballot(surv[0] && !single[0]), mm1 = __ballot(surv[1] && !single[1]);
         const uint32_t cs0 = (uint32_t)__popcll(ms0), cs1 = (uint32_t)__popcll(ms1);
         const uint32_t cm0 = (uint32_t)__popcll(mm0), cm1 = (uint32_t)__popcll(mm1);
-        unsigned long long wb = 0;
-        if ((tid & 63) == 0 && (cs0 + cs1 + cm0 + cm1))
-            wb = atomicAdd(&qn2, ((unsigned long long)(cm0 + cm1) << 32) | (unsigned long long)(cs0 + cs1));
-        const uint32_t fbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wb);
-        const uint32_t bbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wb >> 32));
+        const int wave = tid >> 6;
+        const uint32_t rbase = 128u * (uint32_t)wave;                                    // first slot of the wave's region
+        const uint32_t rlast = min((uint32_t)SEG, rbase + 128u) - 1u;                    // its last slot
+        if ((tid & 63) == 0) wq[wave] = ((cm0 + cm1) << 16) | (cs0 + cs1);
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
             if (surv[u]) {
                 const unsigned long long m = single[u] ? (u ? ms1 : ms0) : (u ? mm1 : mm0);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                const uint32_t slot = single[u] ? fbase + (u ? cs0 : 0u) + rank
-                                                : (uint32_t)(SEG - 1) - (bbase + (u ? cm0 : 0u) + rank);
+                const uint32_t slot = single[u] ? rbase + (u ? cs0 : 0u) + rank : rlast - ((u ? cm0 : 0u) + rank);
                 qa[slot] = make_float4(x1[u], y1[u], x2[u], y2[u]);
                 qb[slot] = make_float4(x3[u], y3[u], z1[u], z2[u]);
                 qd[slot] = make_uint2(__float_as_uint(z3[u]), (uint32_t)(u * EMIT_ACTIVE + tid));
             }
         }
     }
+    pr.template stamp<2>();   // compaction done
     __syncthreads();
+    pr.template stamp<3>();
 
     // ---------------- phase B: dense lanes, one surviving triangle each ----------------
-    const unsigned long long q2 = qn2;
-    const int nqf = (int)(uint32_t)q2, nq = nqf + (int)(uint32_t)(q2 >> 32);
+    // the dense list: the four waves' single-pixel survivors, then their multi-pixel ones (queue_slot maps list index -> slot)
+    const uint32_t w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
+    const int f1 = (int)(w0 & 0xFFFFu), f2 = f1 + (int)(w1 & 0xFFFFu), f3 = f2 + (int)(w2 & 0xFFFFu),
+              nqf = f3 + (int)(w3 & 0xFFFFu);
+    const int m1 = nqf + (int)(w0 >> 16), m2 = m1 + (int)(w1 >> 16), m3 = m2 + (int)(w2 >> 16), nq = m3 + (int)(w3 >> 16);
+    auto queue_slot = [&](int qi) -> int {
+        if (qi < nqf) {  // front of wave w's region
+            const int w = (qi >= f1) + (qi >= f2) + (qi >= f3);
+            return 128 * w + (qi - (w == 0 ? 0 : w == 1 ? f1 : w == 2 ? f2 : f3));
+        }
+        const int w = (qi >= m1) + (qi >= m2) + (qi >= m3);
+        return min(SEG, 128 * w + 128) - 1 - (qi - (w == 0 ? nqf : w == 1 ? m1 : w == 2 ? m2 : m3));
+    };
     for (int qi = tid; qi < nq; qi += EMIT_BLOCK) {
-        const int sl = qi < nqf ? qi : SEG - 1 - (qi - nqf);  // front part, then the back part (densely packed lanes)
+        const int sl = queue_slot(qi);
         const float4 A4 = qa[sl], B4 = qb[sl];
         const uint2 D2 = qd[sl];
         const float x1 = A4.x, y1 = A4.y, x2 = A4.z, y2 = A4.w, x3 = B4.x, y3 = B4.y;
@@ -703,7 +729,9 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
         }
         qd[sl].x = tag;
     }
+    pr.template stamp<4>();   // phase B done
     __syncthreads();
+    pr.template stamp<5>();
     // ---------------- phase C: bucket offsets, records out ----------------
     // (one wave scans, the other three wait at the barrier: a variant in which every wave scans for itself and reads the
     // bucket base with a cross-lane shuffle -- no third barrier -- measured 2 us SLOWER per launch, A/B in one process)
@@ -723,10 +751,11 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
         }
     }
     __syncthreads();
+    pr.template stamp<6>();
     uint4* R = a.recs + ((size_t)b * a.nseg + seg) * SEG;
     float4* Rn = a.recn + ((size_t)b * a.nseg + seg) * SEG;
     for (int qi = tid; qi < nq; qi += EMIT_BLOCK) {
-        const int sl = qi < nqf ? qi : SEG - 1 - (qi - nqf);
+        const int sl = queue_slot(qi);
         const uint32_t tag = qd[sl].x;
         if (tag != 0xFFFFFFFFu) {
             const float4 r = qa[sl];
@@ -735,6 +764,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             Rn[slot] = qb[sl];
         }
     }
+    pr.finish(nq);
 }
 
 // ---- binned path, kernel 2: per (face, strip) LDS resolve + output ----------------------------------------
@@ -1383,20 +1413,16 @@ int fr_launch_rendering_layer(const float* vertex, const float* tri, const float
                               net_in, depth_img, workspace, ws_bytes, stream);
 }
 
-static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
-                              int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
-                              const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
-                              hipStream_t stream, int phases, long long vpitch) {
+// Argument block + geometry of one forward call (everything the kernels read); *binned = the binned rasteriser serves it.
+static int prepare_render(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H, int W,
+                          int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind, const float* im_gray,
+                          float* net_in, float* depth_img, void* workspace, size_t ws_bytes, long long vpitch,
+                          fr::RenderArgs& a, RenderGeom& g, bool* binned_out) {
     using namespace fr;
     const bool fused = net_in != nullptr;
-    constexpr int BLOCK = 1024;
-    if (nver == 0) ntri = 0;  // no vertex can be valid: every triangle is skipped, the planes are pure background
     if ((size_t)W * sizeof(unsigned long long) > kLdsMax) return FR_ERR_UNSUPPORTED;
-    RenderGeom g = render_geom(B, ntri, H, W);
-    long long nbins = (long long)B * g.strips;
-    if (nbins > 0x7FFFFFFFll) return FR_ERR_UNSUPPORTED;
-
-    RenderArgs a;
+    g = render_geom(B, ntri, H, W);
+    if ((long long)B * g.strips > 0x7FFFFFFFll) return FR_ERR_UNSUPPORTED;
     a.vertex = vertex; a.tri = tri; a.texture = texture;
     a.vpitch = vpitch > 0 ? vpitch : nver;
     a.depth = depth; a.tex_img = tex_img; a.normal = normal; a.tri_ind = tri_ind;
@@ -1411,18 +1437,11 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     a.resolve_opt = opt(OPT_RESOLVE_OPT);
     a.use_filter = opt(OPT_EMIT_FILTER);  // bit 0: certified fp32 inside test, bit 1: single-pixel pre-cull in phase A
     a.rows_magic = g.rows > 1 ? (uint32_t)((0x100000000ull + (unsigned)g.rows - 1) / (unsigned)g.rows) : 0u;
-
-    const bool binned = g.binned_ok && ntri > 0 && opt(OPT_RENDER_IMPL) != 1;
-    if (fused && !binned) return FR_ERR_UNSUPPORTED;  // the caller falls back to the unfused op + elementwise post-processing
     a.tri4 = nullptr; a.nseg_magic = 0;
-    if (!binned) {
-        if (!(phases & 2)) return FR_OK;  // the fallback is a single kernel: it counts as the resolve phase
-        static unsigned char lds_ok[64];
-        if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_strip_kernel<BLOCK>), lds_ok) != hipSuccess)
-            return FR_ERR_LAUNCH;
-        hipLaunchKernelGGL(render_strip_kernel<BLOCK>, dim3((unsigned)nbins), dim3(BLOCK), g.lds, stream, a);
-        return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
-    }
+    const bool binned = g.binned_ok && ntri > 0 && opt(OPT_RENDER_IMPL) != 1;
+    *binned_out = binned;
+    if (fused && !binned) return FR_ERR_UNSUPPORTED;  // the caller falls back to the unfused op + elementwise post-processing
+    if (!binned) return FR_OK;
     if (ws_bytes < g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes + g.tri4_bytes || !workspace ||
         ((uintptr_t)workspace & 15))
         return FR_ERR_WORKSPACE;
@@ -1431,16 +1450,43 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     a.segoff = reinterpret_cast<uint16_t*>(wsp + g.recs_bytes);
     a.recn = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes);
     a.tritex_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes + g.nrm_bytes);
-    int4* tri4 = reinterpret_cast<int4*>(wsp + g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes);
-    a.tri4 = tri4;
+    a.tri4 = reinterpret_cast<int4*>(wsp + g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes);
     // lid / nseg through the 2^32 reciprocal is exact while lid * (magic * nseg - 2^32) < 2^32, i.e. B * nseg^2 < 2^32
     a.nseg_magic = ((unsigned long long)B * g.nseg * g.nseg < 0x100000000ull && g.nseg > 1)
                        ? (uint32_t)((0x100000000ull + (unsigned)g.nseg - 1) / (unsigned)g.nseg) : 0u;
-    if (phases & 4)
+    return FR_OK;
+}
+
+static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
+                              int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
+                              const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
+                              hipStream_t stream, int phases, long long vpitch) {
+    using namespace fr;
+    const bool fused = net_in != nullptr;
+    constexpr int BLOCK = 1024;
+    if (nver == 0) ntri = 0;  // no vertex can be valid: every triangle is skipped, the planes are pure background
+    RenderArgs a;
+    RenderGeom g;
+    bool binned = false;
+    const int prc = prepare_render(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, im_gray,
+                                   net_in, depth_img, workspace, ws_bytes, vpitch, a, g, &binned);
+    if (prc != FR_OK) return prc;
+    const long long nbins = (long long)B * g.strips;
+    if (!binned) {
+        if (!(phases & 2)) return FR_OK;  // the fallback is a single kernel: it counts as the resolve phase
+        static unsigned char lds_ok[64];
+        if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_strip_kernel<BLOCK>), lds_ok) != hipSuccess)
+            return FR_ERR_LAUNCH;
+        hipLaunchKernelGGL(render_strip_kernel<BLOCK>, dim3((unsigned)nbins), dim3(BLOCK), g.lds, stream, a);
+        return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
+    }
+    if (phases & 4) {
+        int4* tri4 = const_cast<int4*>(a.tri4);
         hipLaunchKernelGGL(pack_tri_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, tri, nver, ntri, tri4,
                            tri4 + (size_t)g.nseg * SEG);
+    }
     if (phases & 1)
-        hipLaunchKernelGGL(raster_emit_kernel, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL(raster_emit_kernel<NoEmitProbe>, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
     if (!(phases & 2)) return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
     // 256-thread resolvers when several of them fit a CU's LDS side by side, 512 threads for wide strips
     const int rblk = opt(OPT_RESOLVE_BLOCK) > 0 ? opt(OPT_RESOLVE_BLOCK) : (g.lds <= 32 * 1024 ? 256 : 512);

@@ -1,0 +1,51 @@
+// Development probe for raster_emit_kernel (csrc/fr_render.hip) -- NOT part of the product library.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -mllvm -amdgpu-atomic-optimizer-strategy=None -fPIC -shared \
+//         -o tools/libemit_probe.so tools/emit_probe.hip
+// Exports fr_probe_emit_stamps: launches a stamped build of the emit kernel on the caller's (real) inputs -- every wave
+// records s_memtime at the phase boundaries -- and leaves [workgroups][4 waves][10] stamps in a caller buffer.  Driven by
+// tools/emit_probe.py, which reduces the stamps to the phase shares of a workgroup's life.
+#include "../3dfacerecon_amd/csrc/fr_render.hip"
+
+namespace fr { int opt(Opt o) { return o == OPT_RESOLVE_OPT ? 1 : o == OPT_EMIT_FILTER ? 3 : 0; } }
+
+__device__ unsigned long long* g_emit_stamps;
+
+__device__ __forceinline__ unsigned long long estamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+struct EmitStampProbe {
+    unsigned long long t[8];
+    __device__ __forceinline__ void begin() { t[0] = estamp(); }
+    template <int ID> __device__ __forceinline__ void stamp() { t[ID + 1] = estamp(); }
+    __device__ __forceinline__ void finish(int nq) {
+        const unsigned long long te = estamp();
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* o = g_emit_stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 10;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[i] = t[i];
+            o[8] = te;
+            o[9] = (unsigned long long)nq;
+        }
+    }
+};
+
+extern "C" int fr_probe_emit_stamps(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
+                                    int H, int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
+                                    void* workspace, size_t ws_bytes, long long vpitch, unsigned long long* stamps,
+                                    void* hip_stream) {
+    using namespace fr;
+    RenderArgs a;
+    RenderGeom g;
+    bool binned = false;
+    int rc = prepare_render(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr, nullptr,
+                            nullptr, workspace, ws_bytes, vpitch, a, g, &binned);
+    if (rc != FR_OK || !binned) return rc ? rc : -100;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_emit_stamps), &stamps, sizeof(stamps));
+    hipLaunchKernelGGL(raster_emit_kernel<EmitStampProbe>, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0,
+                       (hipStream_t)hip_stream, a);
+    return hipGetLastError() == hipSuccess ? B * g.nseg : FR_ERR_LAUNCH;
+}

@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
-"""Development probe: emit-kernel A/B knobs in one process, interleaved rounds (FR_EMIT_FILTER: certified fp32 inside test)."""
+"""Development probe of raster_emit_kernel on the bench workload (64 faces, 200x200, BFM-scale mesh):
+  (1) A/B of the launcher knobs in one process, interleaved rounds (fr_set_option: FR_EMIT_FILTER), outputs compared;
+  (2) the stamped build (tools/libemit_probe.so from tools/emit_probe.hip): every wave's s_memtime at the phase
+      boundaries -> shares of a workgroup's life per phase (median over all 13,440 workgroups), printed as JSON.
+Build the probe library first (command in tools/emit_probe.hip)."""
+import ctypes
 import importlib
+import json
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
@@ -15,15 +22,15 @@ def pkg(n):
 
 
 def main():
-    B, S, K = 64, 200, 200
-    synth, netm, pipe = pkg("utils.synth"), pkg("nets.network"), pkg("pipeline")
+    B, S, K = 64, 200, 100
+    synth, netm, pipe, host = pkg("utils.synth"), pkg("nets.network"), pkg("pipeline"), pkg("_lib")
     dev = torch.device("cuda:0")
     A = synth.make_assets()
     net = netm.FaceRecNet(mesh_data=A, batch_size=B, im_size=S, device=dev)
     plan = pipe.DecodeRenderPlan(net, B, S, S)
-    plan.params.copy_(torch.as_tensor(synth.sample_params_batch(B, im_size=S, beta=0.7), device=dev))
-    os.environ["FR_EMIT_FILTER"] = "0"
-    ref = [o.clone() for o in plan.step()]
+    plan.params.copy_(torch.as_tensor(synth.sample_params_batch(B, im_size=S, beta=0.7, seed=3456), device=dev))
+    with host.options(FR_EMIT_FILTER=0):
+        ref = [o.clone() for o in plan.step()]
     torch.cuda.synchronize()
 
     def wall(fn):
@@ -36,16 +43,59 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / K * 1e6
 
-    res = {"1": [], "3": []}
-    for rnd in range(5):
-        for v in ("1", "3"):
-            os.environ["FR_EMIT_FILTER"] = v
-            outs = plan.step()
-            torch.cuda.synchronize()
-            assert all(torch.equal(a, b) for a, b in zip(outs, ref))
-            res[v].append((round(wall(lambda: plan.render_phase(1)), 1), round(wall(plan.step), 1)))
-    for v in ("1", "3"):
-        print("FR_EMIT_FILTER=%s (emit alone us, step us): %s" % (v, res[v]), flush=True)
+    out = {"ab_us": {}}
+    res = {1: [], 3: []}
+    for rnd in range(3):
+        for v in (1, 3):
+            with host.options(FR_EMIT_FILTER=v):
+                outs = plan.step()
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, b) for a, b in zip(outs, ref))
+                res[v].append((round(wall(lambda: plan.render_phase(1)), 1), round(wall(plan.step), 1)))
+    for v in (1, 3):
+        out["ab_us"]["FR_EMIT_FILTER=%d (emit alone, step)" % v] = res[v]
+
+    # ---- stamps -------------------------------------------------------------------------------------------------------
+    so = os.path.join(ROOT, "tools", "libemit_probe.so")
+    if os.path.exists(so):
+        P = ctypes.CDLL(so)
+        vp, i = ctypes.c_void_p, ctypes.c_int
+        P.fr_probe_emit_stamps.argtypes = [vp, vp, vp, i, i, i, i, i, i, vp, vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_longlong,
+                                           vp, vp]
+        P.fr_probe_emit_stamps.restype = i
+        nwg_max = B * 256
+        stamps = torch.zeros((nwg_max * 4 * 10,), dtype=torch.int64, device=dev)
+        p = host.ptr
+        for _ in range(50):
+            plan.step()
+        torch.cuda.synchronize()
+        nwg = P.fr_probe_emit_stamps(p(plan._vertex), p(net.tri), p(plan.texture), B, plan.N, plan.T, S, S, plan.tex_batch,
+                                     p(plan.depth), p(plan.texture_image), p(plan.normal), p(plan.tri_ind), p(plan._ws),
+                                     plan._ws_bytes, plan.pitch, p(stamps),
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert nwg > 0, nwg
+        plan.render_phase(2)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(plan.outputs(), ref)), "stamped build changed the records"
+        st = stamps.cpu().numpy().reshape(-1, 4, 10)[:nwg].astype(np.float64)
+        t = st[:, :, :9]
+        nq = st[:, 0, 9]
+        seg = np.diff(t, axis=2)                      # [wg, wave, 8 segments]
+        names = ["entry -> counters zeroed + barrier", "A: table + 18 gathers + bbox + single-pixel pre-cull",
+                 "A: compaction into the LDS queue", "barrier 1", "B: depth / inside test / normal / LDS record",
+                 "barrier 2", "C: bucket scan (wave 0) + barrier 3", "C: records out"]
+        life = t[:, :, 8] - t[:, :, 0]
+        rep = {"workgroups": int(nwg), "survivors_per_workgroup_median": float(np.median(nq)),
+               "wave_life_cycles_median": float(np.median(life)), "segments_cycles_median_over_waves": {},
+               "segments_share_of_wave_life": {}}
+        for k, nm in enumerate(names):
+            rep["segments_cycles_median_over_waves"][nm] = float(np.median(seg[:, :, k]))
+            rep["segments_share_of_wave_life"][nm] = float(np.mean(seg[:, :, k]) / np.mean(life))
+        # phase B by wave index (the queue is dense: waves 2-3 usually have nothing to do)
+        rep["phase_B_cycles_median_by_wave"] = [float(np.median(seg[:, w, 4])) for w in range(4)]
+        out["stamps"] = rep
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
