@@ -319,6 +319,9 @@ __device__ __forceinline__ void ring_wait(f32x4& slot) {
 // leaves VGPRs free on purpose: the 8-wave form (WPE = 4: <= 128 VGPRs, half the register file) lets the render
 // kernels of the previous batch share the CU with the decode of the next one (pipeline.py, PipelinedPlan).
 // NT: the basis stream is requested with the non-temporal hint (read once per launch by one CU pair of waves).
+// (Measured and rejected in round 3, profiles/round3_probes/r3s12_decode_ab_balanced_tail.json: dealing the last, partial
+// round of tile pairs as single tiles cut into four 16-column quarter items, one per SIMD -- 6.5 items on every SIMD instead
+// of 7 on half of the CUs and 6 on the others: 55.1 vs 55.0 us, the matrix pipe's balance is not what bounds the kernel.)
 // PRIO: static issue priorities for the four waves that share a SIMD (waves w, w+4, w+8, w+12 get 0..3): with equal
 // priorities the sixteen waves of a CU advance in lock-step and reach their epilogues together; ranked, a SIMD tends to run
 // them one after the other, which spreads the epilogues and their stores (decode -1 us dense, -2 us with aligned rows).
