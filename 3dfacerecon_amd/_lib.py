@@ -160,6 +160,13 @@ def _bind(L):
     L.fr_decode_3dmm_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp,
                                           ctypes.c_size_t, _vp]
     L.fr_decode_3dmm_backward.restype = _i
+    L.fr_decode_backward_basis_bytes.argtypes = [_i, _i, _i]
+    L.fr_decode_backward_basis_bytes.restype = ctypes.c_size_t
+    L.fr_decode_backward_pack_basis.argtypes = [_vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]
+    L.fr_decode_backward_pack_basis.restype = _i
+    L.fr_decode_3dmm_backward_packed.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp,
+                                                 ctypes.c_size_t, _vp]
+    L.fr_decode_3dmm_backward_packed.restype = _i
     L.fr_debug_render_geom.argtypes = [_i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int)]
     L.fr_debug_render_geom.restype = None
     L.fr_debug_div3_sweep.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]
@@ -173,7 +180,8 @@ EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_r
            "fr_render_depth_forward_phases", "fr_debug_render_geom", "fr_debug_div3_sweep",
            "fr_render_depth_backward_workspace_bytes", "fr_render_depth_backward_ws", "fr_set_option", "fr_get_option",
            "fr_decode_q30_image_bytes", "fr_decode_q30_pack", "fr_decode_q30_workspace_bytes", "fr_decode_3dmm_q30",
-           "fr_decode_render_vertex_pitch", "fr_decode_render_vertex_bytes", "fr_decode_render_forward"]
+           "fr_decode_render_vertex_pitch", "fr_decode_render_vertex_bytes", "fr_decode_render_forward",
+           "fr_decode_backward_basis_bytes", "fr_decode_backward_pack_basis", "fr_decode_3dmm_backward_packed"]
 
 
 def lib():

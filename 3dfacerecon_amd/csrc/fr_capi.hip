@@ -271,4 +271,33 @@ int fr_decode_3dmm_backward(const float* grad_vertex_proj, const float* params, 
                                      n_exp, im_size, grad_params, workspace, (hipStream_t)hip_stream);
 }
 
+size_t fr_decode_backward_basis_bytes(int N, int n_shape, int n_exp) {
+    if (N <= 0 || n_shape < 0 || n_exp < 0) return 0;
+    return fr_decode_backward_basis_bytes_impl(N, n_shape, n_exp);
+}
+
+int fr_decode_backward_pack_basis(const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp, void* packed_t,
+                                  size_t packed_bytes, void* hip_stream) {
+    if (N < 0 || n_shape < 0 || n_exp < 0) return FR_ERR_INVALID_ARG;
+    if (packed_bytes < fr_decode_backward_basis_bytes(N, n_shape, n_exp)) return FR_ERR_WORKSPACE;
+    if (N == 0 || n_shape + n_exp == 0) return FR_OK;
+    if (!packed_t || (n_shape > 0 && !pc_shape) || (n_exp > 0 && !pc_exp)) return FR_ERR_INVALID_ARG;
+    if (((uintptr_t)packed_t & 15) != 0) return FR_ERR_INVALID_ARG;
+    return fr_launch_decode_backward_pack(pc_shape, pc_exp, N, n_shape, n_exp, packed_t, (hipStream_t)hip_stream);
+}
+
+int fr_decode_3dmm_backward_packed(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
+                                   const void* packed_t, const float* R_override, int B, int N, int n_shape, int n_exp,
+                                   float im_size, float* grad_params, void* workspace, size_t ws_bytes, void* hip_stream) {
+    if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0) return FR_ERR_INVALID_ARG;
+    if (B == 0) return FR_OK;
+    if (!grad_params || !params) return FR_ERR_INVALID_ARG;
+    if (N > 0 && (!grad_vertex_proj || !vertex_proj || (n_shape + n_exp > 0 && !packed_t))) return FR_ERR_INVALID_ARG;
+    if (((uintptr_t)packed_t & 15) != 0) return FR_ERR_INVALID_ARG;
+    if (ws_bytes < fr_decode_backward_workspace_bytes(B, N, n_shape, n_exp)) return FR_ERR_WORKSPACE;
+    if (N > 0 && (!workspace || ((uintptr_t)workspace & 15))) return FR_ERR_WORKSPACE;
+    return fr_launch_decode_backward(grad_vertex_proj, params, vertex_proj, nullptr, nullptr, R_override, B, N, n_shape, n_exp,
+                                     im_size, grad_params, workspace, (hipStream_t)hip_stream, n_shape + n_exp > 0 ? packed_t : nullptr);
+}
+
 }  // extern "C"

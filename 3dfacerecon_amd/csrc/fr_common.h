@@ -142,4 +142,8 @@ int fr_device_cu_count();
 size_t fr_decode_backward_workspace_impl(int N, int ns, int ne);
 int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
                               const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N, int ns,
-                              int ne, float im_size, float* grad_params, void* workspace, hipStream_t stream);
+                              int ne, float im_size, float* grad_params, void* workspace, hipStream_t stream,
+                              const void* packed_t = nullptr);
+size_t fr_decode_backward_basis_bytes_impl(int N, int ns, int ne);
+int fr_launch_decode_backward_pack(const float* pc_shape, const float* pc_exp, int N, int ns, int ne, void* packed_t,
+                                   hipStream_t stream);

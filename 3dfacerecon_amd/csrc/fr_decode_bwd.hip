@@ -45,6 +45,11 @@ struct BwdArgs {
     int B, N, ns, ne, b0, nbatch;
     int pre_blocks, gemm_blocks, rows_per_block;
     float im_size;
+    // K-major packed image (fr_decode_backward_pack_basis) and its geometry; null: the reference-layout kernel runs
+    const float4* At;        // [row blocks][slot blocks][64 lanes] float4
+    int sbt, sbs;            // slot blocks of 16 coefficients in all / of the shape basis (expression blocks follow)
+    int rbt, rb_per_block;   // row blocks of 16 rows in all / per gemm workgroup
+    int exp_slot0;           // first coefficient slot of the expression basis in the slabs
 };
 
 __device__ __forceinline__ void bwd_rotation(const BwdArgs& a, int b, float* R9) {
@@ -168,6 +173,11 @@ __global__ __launch_bounds__(256) void bwd_prepass_kernel(BwdArgs a) {
             a.dvT4[((size_t)c * N + pp) * 16 + j4] = make_float4(t[0], t[1], t[2], t[3]);
         }
     }
+    // the pad rows [3N, 16 * row blocks) of the last 16-row block (read as part of a 1 KiB fragment by the packed kernel): zeros
+    if (blockIdx.x == 0) {
+        const long long pad0 = 3ll * N * 16, pad1 = (long long)a.rbt * 256;
+        for (long long i = pad0 + tid; i < pad1; i += 256) a.dvT4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // ---- the reduction over vertices on the matrix cores -------------------------------------------------------------------
@@ -249,6 +259,126 @@ __global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_gemm_kernel(BwdArgs a) {
             }
 }
 
+
+// ---- the same reduction from a K-major packed image (round 3) ---------------------------------------------------------
+// The kernel above reads the basis in its reference layout: 16-byte pieces at a 796-byte row stride, requested a trip at a
+// time and waited for with the compiler's vmcnt(0) -- the two waves that share a SIMD run in lock-step, so every trip
+// exposes a full memory round trip (47 / 70 us at 32 / 64 faces against a 33 us MFMA floor).  With the basis packed ONCE
+// into MFMA A-fragment order (fr_decode_backward_pack_basis: [16-row block][16-coefficient block][lane] float4, element
+// j = basis[16 rb + 4 j + (lane >> 4)][16 sb + (lane & 15)], zero padded) every operand fetch is a coalesced, aligned 1 KiB
+// fragment -- the dv rows of a 16-row block are four such fragments as well -- and the fragments run through a ring of
+// BR row blocks of registers filled by inline-asm loads that the compiler can neither reorder nor drain; the only waits are
+// counted.  Accumulation order per output: rows ascending within the workgroup's row range (as above); the partial
+// slabs are summed by bwd_reduce_kernel in its fixed order.
+__global__ __launch_bounds__(256) void bwd_pack_kernel(const float* __restrict__ pc_shape, const float* __restrict__ pc_exp,
+                                                       int N, int ns, int ne, int sbs, int sbt, long long rbt,
+                                                       float4* __restrict__ At) {
+    const long long rows = 3ll * N;
+    const long long total = rbt * sbt * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const long long q = i >> 6;
+        const int sb = (int)(q % sbt);
+        const long long rb = q / sbt;
+        const int slot = 16 * sb + (lane & 15);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const long long row = 16 * rb + 4 * j + (lane >> 4);
+            float x = 0.f;
+            if (row < rows) {
+                if (sb < sbs) { if (slot < ns) x = pc_shape[(size_t)row * ns + slot]; }
+                else { const int c = slot - 16 * sbs; if (c < ne) x = pc_exp[(size_t)row * ne + c]; }
+            }
+            v[j] = x;
+        }
+        At[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+#define FRB_LD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
+constexpr int BR = 3;   // ring depth in 16-row blocks: 24 fragment loads (24 KiB) in flight per wave
+
+template <int NB>
+__global__ __launch_bounds__(BW_MAXWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void bwd_gemm_ring_kernel(BwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int kq = lane >> 4, jn = lane & 15;
+    const int sbt = a.sbt;
+    const int sb0 = 4 * wave;                              // this wave's four 16-coefficient blocks
+    const int nsb = min(4, sbt - sb0);                     // live ones (wave-uniform, >= 1)
+    const long long rb_begin = (long long)blockIdx.x * a.rb_per_block;
+    const long long rb_end = min((long long)a.rbt, rb_begin + a.rb_per_block);
+    f32x4 acc[4][NB];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int mb = 0; mb < NB; mb++) acc[i][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[BR][4], rbv[BR][4];   // ring: the row block's A fragments (one per coefficient block) and dv fragments (one per k-step)
+    // fragment addresses of row block rb (clamped: a slot past the end re-requests the last block and is never consumed;
+    // a dead coefficient block re-requests block sbt - 1)
+    auto request = [&](int d, long long rb) {
+        const long long rbc = min(rb, (long long)a.rbt - 1);
+        const float4* ab = a.At + ((size_t)rbc * sbt) * 64 + lane;
+        const float4* bb = a.dvT4 + (size_t)rbc * 256 + lane;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4* p = ab + (size_t)min(sb0 + i, sbt - 1) * 64;
+            FRB_LD(ra[d][i], p);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float4* p = bb + (size_t)j * 64;
+            FRB_LD(rbv[d][j], p);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < BR; d++) request(d, rb_begin + d);
+    for (long long rb0 = rb_begin; rb0 < rb_end; rb0 += BR) {
+#pragma unroll
+        for (int d = 0; d < BR; d++) {
+            // the 8 loads of ring slot d are the oldest outstanding ones: all but the 8 (BR - 1) youngest must be back
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(ra[d][0]), "+v"(ra[d][1]), "+v"(ra[d][2]), "+v"(ra[d][3]), "+v"(rbv[d][0]),
+                         "+v"(rbv[d][1]), "+v"(rbv[d][2]), "+v"(rbv[d][3]));
+            static_assert(BR == 3, "the counted wait above is written for three ring slots of eight loads");
+            if (rb0 + d < rb_end) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)        // k-step: rows 16 rb + 4 j .. + 3, ascending
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (i < nsb) {
+#pragma unroll
+                            for (int mb = 0; mb < NB; mb++)
+                                acc[i][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[d][i][j], rbv[d][j][mb], acc[i][mb], 0, 0, 0);
+                        }
+            }
+            request(d, rb0 + d + BR);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < BR; d++)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[d][0]), "+v"(ra[d][1]), "+v"(ra[d][2]), "+v"(ra[d][3]), "+v"(rbv[d][0]),
+                     "+v"(rbv[d][1]), "+v"(rbv[d][2]), "+v"(rbv[d][3]));
+    // D tile of coefficient block i: row m = 4 * (lane >> 4) + reg is slot 64 wave + 16 i + m, column (batch in block) = lane & 15
+    // (staging the tile through LDS so that a store instruction writes four whole 256-byte slab rows instead of four 64-byte
+    // pieces measured no faster: 59.2 vs 58.0 us at 64 faces -- the store tail is not what bounds the kernel)
+    const int nslots = 64 * (int)(blockDim.x >> 6);
+    float* slab = a.slab + (size_t)blockIdx.x * nslots * 64;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < nsb) {
+#pragma unroll
+            for (int mb = 0; mb < NB; mb++)
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    const int slot = 64 * wave + 16 * i + 4 * kq + rg;
+                    slab[(size_t)slot * 64 + 16 * mb + jn] = acc[i][mb][rg];
+                }
+        }
+}
+#undef FRB_LD
+
 // ---- fixed-order reduction of the partials ---------------------------------------------------------------------------------
 // One 1024-thread workgroup per 64 consecutive outputs (output i = what*64 + batch: what 0..3 = d t3d / d f, 4.. = the
 // padded coefficients).  Wave w sums its contiguous 1/16 of the partials with eight independent loads in flight per
@@ -258,7 +388,7 @@ constexpr int RED_WAVES = 16;
 __global__ __launch_bounds__(RED_WAVES * 64) void bwd_reduce_kernel(BwdArgs a) {
     __shared__ float part[RED_WAVES][64];
     const int nd = FR_N_POSE + a.ns + a.ne;
-    const int nslots = 64 * bw_waves(a.ns, a.ne);
+    const int nslots = a.At ? 64 * ((a.sbt + 3) / 4) : 64 * bw_waves(a.ns, a.ne);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int what = blockIdx.x, b = lane;  // i = what * 64 + b
     const float* src;
@@ -309,11 +439,11 @@ __global__ __launch_bounds__(RED_WAVES * 64) void bwd_reduce_kernel(BwdArgs a) {
     } else if (what == 3) {
         gp[6] = tot;
     } else {
-        const int slot = what - 4, ns4 = bw_ns4(a.ns);
-        if (slot < ns4) {
+        const int slot = what - 4, e0 = a.exp_slot0;   // shape slots [0, e0), expression slots from e0
+        if (slot < e0) {
             if (slot < a.ns) gp[FR_N_POSE + slot] = tot;
-        } else if (slot - ns4 < a.ne) {
-            gp[FR_N_POSE + a.ns + slot - ns4] = tot;
+        } else if (slot - e0 < a.ne) {
+            gp[FR_N_POSE + a.ns + slot - e0] = tot;
         }
     }
 }
@@ -321,6 +451,9 @@ __global__ __launch_bounds__(RED_WAVES * 64) void bwd_reduce_kernel(BwdArgs a) {
 struct BwdGeom {
     int pre_blocks, gemm_blocks, rows_per_block;
     size_t dv_bytes, pose_bytes, slab_bytes;
+    // packed-image variant
+    int sbs, sbt, rbt, rb_per_block, gemm_blocks_p, waves_p;
+    size_t slab_bytes_p, at_bytes;
 };
 static BwdGeom bwd_geom(int N, int ns = 199, int ne = 29) {
     BwdGeom g;
@@ -332,7 +465,17 @@ static BwdGeom bwd_geom(int N, int ns = 199, int ne = 29) {
     if (rpb < 4) rpb = 4;
     g.rows_per_block = (int)rpb;
     g.gemm_blocks = (int)((rows + rpb - 1) / rpb);
-    g.dv_bytes = (size_t)rows * 16 * sizeof(float4);
+    // (dv rows padded to whole 16-row blocks: the packed variant reads them as 1 KiB fragments)
+    g.rbt = (int)((rows + 15) / 16);
+    g.dv_bytes = (size_t)g.rbt * 16 * 16 * sizeof(float4);
+    g.sbs = (ns + 15) / 16;
+    g.sbt = g.sbs + (ne + 15) / 16;
+    g.waves_p = (g.sbt + 3) / 4;
+    g.rb_per_block = (int)((g.rbt + 511) / 512);
+    if (g.rb_per_block < 1) g.rb_per_block = 1;
+    g.gemm_blocks_p = g.rbt > 0 ? (g.rbt + g.rb_per_block - 1) / g.rb_per_block : 0;
+    g.slab_bytes_p = (size_t)g.gemm_blocks_p * 64 * g.waves_p * 64 * sizeof(float);
+    g.at_bytes = (size_t)g.rbt * g.sbt * 64 * sizeof(float4);
     g.pose_bytes = (((size_t)g.pre_blocks * 64 * 4 * sizeof(float)) + 15) & ~(size_t)15;
     g.slab_bytes = (size_t)g.gemm_blocks * 64 * bw_waves(ns, ne) * 64 * sizeof(float);
     return g;
@@ -343,20 +486,37 @@ static BwdGeom bwd_geom(int N, int ns = 199, int ne = 29) {
 size_t fr_decode_backward_workspace_impl(int N, int ns, int ne) {
     if (N <= 0) return 0;
     fr::BwdGeom g = fr::bwd_geom(N, ns, ne);
-    return g.dv_bytes + g.pose_bytes + g.slab_bytes;
+    return g.dv_bytes + g.pose_bytes + (g.slab_bytes > g.slab_bytes_p ? g.slab_bytes : g.slab_bytes_p);
+}
+
+size_t fr_decode_backward_basis_bytes_impl(int N, int ns, int ne) {
+    if (N <= 0 || ns + ne <= 0) return 0;
+    return fr::bwd_geom(N, ns, ne).at_bytes;
+}
+
+int fr_launch_decode_backward_pack(const float* pc_shape, const float* pc_exp, int N, int ns, int ne, void* packed_t,
+                                   hipStream_t stream) {
+    using namespace fr;
+    if (N <= 0 || ns + ne <= 0) return FR_OK;
+    BwdGeom g = bwd_geom(N, ns, ne);
+    hipLaunchKernelGGL(bwd_pack_kernel, dim3(2048), dim3(256), 0, stream, pc_shape, pc_exp, N, ns, ne, g.sbs, g.sbt,
+                       (long long)g.rbt, reinterpret_cast<float4*>(packed_t));
+    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
 int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
                               const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N, int ns,
-                              int ne, float im_size, float* grad_params, void* workspace, hipStream_t stream) {
+                              int ne, float im_size, float* grad_params, void* workspace, hipStream_t stream,
+                              const void* packed_t) {
     using namespace fr;
     if (B == 0) return FR_OK;
     const int nd = FR_N_POSE + ns + ne;
     if (N == 0) return hipMemsetAsync(grad_params, 0, (size_t)B * nd * sizeof(float), stream) == hipSuccess ? FR_OK
                                                                                                              : FR_ERR_LAUNCH;
-    const int waves = bw_waves(ns, ne);
-    if (waves > BW_MAXWAVES) return FR_ERR_UNSUPPORTED;  // > 512 coefficient slots
     BwdGeom g = bwd_geom(N, ns, ne);
+    const bool packed = packed_t != nullptr;
+    const int waves = packed ? g.waves_p : bw_waves(ns, ne);
+    if (waves > BW_MAXWAVES) return FR_ERR_UNSUPPORTED;  // > 512 coefficient slots
     BwdArgs a;
     a.g = grad_vertex_proj; a.params = params; a.vproj = vertex_proj;
     a.pc_shape = pc_shape; a.pc_exp = pc_exp; a.R_override = R_override; a.grad_params = grad_params;
@@ -365,13 +525,22 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
     a.pose_part = reinterpret_cast<float*>(ws + g.dv_bytes);
     a.slab = reinterpret_cast<float*>(ws + g.dv_bytes + g.pose_bytes);
     a.B = B; a.N = N; a.ns = ns; a.ne = ne; a.im_size = im_size;
-    a.pre_blocks = g.pre_blocks; a.gemm_blocks = g.gemm_blocks; a.rows_per_block = g.rows_per_block;
+    a.pre_blocks = g.pre_blocks; a.gemm_blocks = packed ? g.gemm_blocks_p : g.gemm_blocks; a.rows_per_block = g.rows_per_block;
+    a.At = reinterpret_cast<const float4*>(packed_t);
+    a.sbt = g.sbt; a.sbs = g.sbs; a.rbt = g.rbt; a.rb_per_block = g.rb_per_block;
+    a.exp_slot0 = packed ? 16 * g.sbs : bw_ns4(ns);
     for (int b0 = 0; b0 < B; b0 += 64) {
         a.b0 = b0;
         a.nbatch = min(B - b0, 64);
         hipLaunchKernelGGL(bwd_prepass_kernel, dim3(g.pre_blocks), dim3(256), 0, stream, a);
         const int nbt = (a.nbatch + 15) / 16;
-        if (waves > 0) {
+        if (waves > 0 && packed) {
+            const dim3 gb(waves * 64);
+            if (nbt == 1) hipLaunchKernelGGL(bwd_gemm_ring_kernel<1>, dim3(a.gemm_blocks), gb, 0, stream, a);
+            else if (nbt == 2) hipLaunchKernelGGL(bwd_gemm_ring_kernel<2>, dim3(a.gemm_blocks), gb, 0, stream, a);
+            else if (nbt == 3) hipLaunchKernelGGL(bwd_gemm_ring_kernel<3>, dim3(a.gemm_blocks), gb, 0, stream, a);
+            else hipLaunchKernelGGL(bwd_gemm_ring_kernel<4>, dim3(a.gemm_blocks), gb, 0, stream, a);
+        } else if (waves > 0) {
             const dim3 gb(waves * 64);
             if (nbt == 1) hipLaunchKernelGGL(bwd_gemm_kernel<1>, dim3(g.gemm_blocks), gb, 0, stream, a);
             else if (nbt == 2) hipLaunchKernelGGL(bwd_gemm_kernel<2>, dim3(g.gemm_blocks), gb, 0, stream, a);

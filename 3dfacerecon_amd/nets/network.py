@@ -57,7 +57,23 @@ class PackedBasis:
                                         h.ptr(self.image), nbytes, h.stream_ptr(device))
         h.check(rc, "fr_decode_pack_basis")
         self._qimage = None
+        self._image_t = None   # K-major image for the backward's reduction over the vertices, built at the first backward
         self.q30_ws_bytes = L.fr_decode_q30_workspace_bytes(ndim_shape, ndim_exp)
+
+    def image_t(self):
+        """The basis packed for the decode backward (fr_decode_backward_pack_basis), built on first use: callers that never
+        take a gradient never hold it."""
+        if self._image_t is None:
+            h = _host()
+            L = h.lib()
+            nbytes = L.fr_decode_backward_basis_bytes(self.nvert, self.ndim_shape, self.ndim_exp)
+            buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = L.fr_decode_backward_pack_basis(h.ptr(self.pc_shape), h.ptr(self.pc_exp), self.nvert, self.ndim_shape,
+                                                     self.ndim_exp, h.ptr(buf), nbytes, h.stream_ptr(self.device))
+            h.check(rc, "fr_decode_backward_pack_basis")
+            self._image_t = buf
+        return self._image_t
 
     def use_q30(self):
         """True when the Q30 entry point serves this call: selected AND the shape is covered (else the f32 chain)."""
@@ -109,6 +125,7 @@ class _Decode3DMM(torch.autograd.Function):
         im_size = float(net.im_size if im_size is None else im_size)
         basis.decode(params, R, B, im_size, out)
         ctx.net = net
+        ctx.basis = basis
         ctx.im_size = im_size
         ctx.save_for_backward(params, out, R if R is not None else params.new_empty(0))
         ctx.has_R = R is not None
@@ -126,10 +143,12 @@ class _Decode3DMM(torch.autograd.Function):
         with torch.cuda.device(params.device):
             nws = L.fr_decode_backward_workspace_bytes(B, net.nvert, net.ndim_shape, net.ndim_exp)
             ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=params.device)
-            rc = L.fr_decode_3dmm_backward(h.ptr(g), h.ptr(params), h.ptr(out), h.ptr(net.pc_shape), h.ptr(net.pc_exp),
-                                           h.ptr(R) if ctx.has_R else None, B, net.nvert, net.ndim_shape, net.ndim_exp,
-                                           ctx.im_size, h.ptr(gp), h.ptr(ws), nws, h.stream_ptr(params.device))
-        h.check(rc, "fr_decode_3dmm_backward")
+            # (the reduction over the vertices streams the K-major packed image: built once per basis, at the first backward)
+            rc = L.fr_decode_3dmm_backward_packed(h.ptr(g), h.ptr(params), h.ptr(out), h.ptr(ctx.basis.image_t()),
+                                                  h.ptr(R) if ctx.has_R else None, B, net.nvert, net.ndim_shape,
+                                                  net.ndim_exp, ctx.im_size, h.ptr(gp), h.ptr(ws), nws,
+                                                  h.stream_ptr(params.device))
+        h.check(rc, "fr_decode_3dmm_backward_packed")
         return gp, None, None, None, None
 
 

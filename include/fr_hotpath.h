@@ -197,6 +197,21 @@ int fr_decode_3dmm_backward(const float* grad_vertex_proj, const float* params, 
                             int n_shape, int n_exp, float im_size, float* grad_params, void* workspace, size_t ws_bytes,
                             void* hip_stream);
 
+/* The same gradient with the basis in a K-major packed image (round 3).  fr_decode_3dmm_backward above reads pc_shape /
+ * pc_exp in their reference layouts (no extra memory; 16-byte pieces at a 796-byte row stride: 70 us at 64 faces against a
+ * 33 us matrix-pipe floor); a caller that takes gradients every step packs the basis ONCE into MFMA A-fragment order for
+ * the reduction over the vertices -- fr_decode_backward_basis_bytes(N, n_shape, n_exp) bytes (the size of the forward image),
+ * 16-byte aligned -- and calls the packed entry point, whose operand fetches are coalesced 1 KiB fragments through a
+ * counted-wait register ring.  Same workspace (fr_decode_backward_workspace_bytes), same definition of every output,
+ * deterministic; the two entry points sum their partial results in different (each fixed) orders, so they agree to
+ * rounding, not bit for bit. */
+size_t fr_decode_backward_basis_bytes(int N, int n_shape, int n_exp);
+int fr_decode_backward_pack_basis(const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp, void* packed_t,
+                                  size_t packed_bytes, void* hip_stream);
+int fr_decode_3dmm_backward_packed(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
+                                   const void* packed_t, const float* R_override, int B, int N, int n_shape, int n_exp,
+                                   float im_size, float* grad_params, void* workspace, size_t ws_bytes, void* hip_stream);
+
 /* ---- test hook ---------------------------------------------------------------------------------------------
  * The screen-bin geometry the forward launcher chooses for a shape (no GPU needed): out = {rows per strip, strips,
  * triangle segments, 1 if the binned path covers the shape else 0 (the strip-scan fallback runs)}.  rows_override > 0

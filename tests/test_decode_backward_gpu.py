@@ -99,3 +99,51 @@ def test_zero_focal_column(oracle, synth):
     for sl in (slice(3, 6), slice(6, 7), slice(7, None)):
         scale = np.abs(want[:, sl]).max() + 1e-30
         assert np.abs(got[keep][:, sl] - want[:, sl]).max() / scale < 2e-5
+
+
+def test_packed_and_reference_layout_entry_points(oracle, synth):
+    """fr_decode_3dmm_backward (basis in its reference layout, no extra memory) and fr_decode_3dmm_backward_packed (K-major
+    image, counted-wait ring: the one the autograd node uses) are the same gradient with differently ordered -- each fixed --
+    partial sums: both within tolerance of the float64 gradient, each bit-reproducible, at a ragged shape (N = 187: the last
+    16-row block of the packed image and of dv is padding; 217 coefficients: 14 + 1 blocks, the last wave has 3 live) and at
+    the model's 199 + 29 with 70 faces (two passes)."""
+    import ctypes
+    from conftest import pkg
+    h = pkg("_lib")
+    L = h.lib()
+    for gu, gv, ns, ne, B in ((11, 17, 200, 17, 5), (13, 17, 199, 29, 70), (7, 9, 3, 0, 2)):
+        A = synth.make_assets(gu, gv, ns, ne, patch=None, seed_basis=gu * gv)
+        N = gu * gv
+        rs = np.random.RandomState(N + B)
+        P = _params(rs, B, ns, ne)
+        G = rs.standard_normal((B, 3, N)).astype(np.float32)
+        net = net_mod().FaceRecNet(mesh_data=A, batch_size=B, im_size=200)
+        dev = torch.device("cuda:0")
+        p = torch.as_tensor(P, device=dev)
+        g = torch.as_tensor(G, device=dev)
+        V = net.vertices_transform(p).detach()
+        nws = L.fr_decode_backward_workspace_bytes(B, N, ns, ne)
+        ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        outs = []
+        for packed in (False, True, True, False):
+            gp = torch.full_like(p, 7.0)
+            if packed:
+                rc = L.fr_decode_3dmm_backward_packed(h.ptr(g), h.ptr(p), h.ptr(V), h.ptr(net._basis.image_t()), None, B, N, ns,
+                                                      ne, 200.0, h.ptr(gp), h.ptr(ws), nws, st)
+            else:
+                rc = L.fr_decode_3dmm_backward(h.ptr(g), h.ptr(p), h.ptr(V), h.ptr(net.pc_shape), h.ptr(net.pc_exp), None, B, N,
+                                               ns, ne, 200.0, h.ptr(gp), h.ptr(ws), nws, st)
+            assert rc == 0
+            torch.cuda.synchronize()
+            outs.append(gp.cpu().numpy().astype(np.float64))
+        np.testing.assert_array_equal(outs[0], outs[3])      # each entry point reproduces its own bits
+        np.testing.assert_array_equal(outs[1], outs[2])
+        want = oracle.decode_3dmm_backward_f64(G, P, A["mu"], A["pc_shape"], A["pc_exp"])
+        for got in (outs[0], outs[1]):
+            assert np.all(got[:, 0:3] == 0)
+            for sl in (slice(3, 6), slice(6, 7), slice(7, 7 + ns), slice(7 + ns, None)):
+                if sl.start >= got.shape[1]:
+                    continue
+                scale = np.abs(want[:, sl]).max() + 1e-30
+                assert np.abs(got[:, sl] - want[:, sl]).max() / scale < 2e-5, (gu, gv, ns, ne, sl)
