@@ -6,7 +6,8 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one 64-face batch of synthetic 235-d parameters already resident in
-HBM: fr_decode_3dmm -> fr_render_depth_forward (all four output planes), through the C ABI, on the BFM-scale
+HBM: fr_decode_render_forward = fr_decode_3dmm -> fr_render_depth_forward (all four output planes; the vertices handed over
+in the library's pitched rows), through the C ABI, on the BFM-scale
 synthetic assets of SURVEY.md 8(d) (N = 53,215, T = 105,840, 199 + 29 components).  Every rank runs its own 64
 faces (weak scaling; the path has no collective), the K steps are bracketed by barrier + synchronize, the MAX
 over ranks is taken and rank 0 prints ONE JSON line.
@@ -178,7 +179,7 @@ def parity_gate(plan, net, assets, params_np, H, W, n_faces):
     frac_equal = float((ulp == 0).mean())
     max_ulp = int(ulp.max())
     ok = bad_planes == 0 and bad_decode == 0 and max_ulp <= 2 and frac_equal >= 0.99
-    return {"faces": n, "route": "DecodeRenderPlan (fr_decode_3dmm + fr_render_depth_forward_phases(3))",
+    return {"faces": n, "route": "DecodeRenderPlan (fr_decode_render_forward, phases 8|1|2 on a triangle table packed once)",
             "mismatching_planes": bad_planes, "planes_checked": 4 * n,
             "decode_host_rotation_mismatching_faces": bad_decode,
             "decode_inkernel_rotation": {"max_ulp": max_ulp, "frac_bit_equal": frac_equal, "bar": "<= 2 ulp, >= 0.99 equal"},
@@ -358,14 +359,14 @@ def main():
                            "achieved": ab["decode"] * B / (decode_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "traffic": None, "avg_ms": decode_ms, "algorithmic_bytes_per_launch": ab["decode"] * B}
         else:
-            roof_decode = {"bound": "mfma", "kernel": "decode_ring_kernel<13,2,8,2,16,64> (fr_decode_3dmm)",
+            roof_decode = {"bound": "mfma", "kernel": "decode_ring_kernel<13,2,8,2,16,64,4,nt,prio> (fr_decode_render_forward, phase 8)",
                            "achieved": flops / (decode_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "traffic": None, "avg_ms": decode_ms, "algorithmic_flop_per_launch": flops,
                            "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9}
-        roof_emit = {"bound": "hbm", "kernel": "raster_emit_kernel (fr_render_depth_forward, phase 1)",
+        roof_emit = {"bound": "hbm", "kernel": "raster_emit_kernel (fr_decode_render_forward, phase 1)",
                      "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "traffic": None, "avg_ms": emit_ms, "algorithmic_bytes_per_launch": emit_bytes}
-        roof_resolve = {"bound": "hbm", "kernel": "resolve_write_kernel<256> (fr_render_depth_forward, phase 2)",
+        roof_resolve = {"bound": "hbm", "kernel": "resolve_write_kernel<256> (fr_decode_render_forward, phase 2)",
                         "achieved": resolve_bytes / (resolve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "traffic": None, "avg_ms": resolve_ms, "algorithmic_bytes_per_launch": resolve_bytes}
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json:
@@ -409,7 +410,7 @@ def main():
                                    + ", no data-path collective",
                        "decode_arith": "q30 (exact fixed point on the int8 MFMA)" if q30 else "f32 fmaf chain (f32-input MFMA)",
                        "constants": "the packed basis (fr_decode_pack_basis) and the pre-validated triangle table "
-                                    "(fr_render_depth_forward_phases, phase 4) are built once per plan: both are "
+                                    "(fr_decode_render_forward, phase 4) are built once per plan: both are "
                                     "tf.constants of the reference model (network.py:41-43, 178); a caller that repacks the "
                                     "triangle list every call (fr_render_depth_forward) pays one more 5 us kernel per step"},
             "roofline": dominant,

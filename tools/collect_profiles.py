@@ -39,6 +39,7 @@ for j in ("bench", "bench_k20", "bench_graph", "bench_q30"):
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.json" % (tag, j)))
 kernel_stats("prof_bench", "%s_kernel_stats.csv" % tag)
+kernel_stats("prof_bwd", "%s_decode_bwd_kernel_stats.csv" % tag)
 # the bench line printed by the SAME process the kernel stats come from (profiled: lower clocks, per-launch overhead)
 f = os.path.join(src, "prof_bench.log")
 if os.path.exists(f):
@@ -74,9 +75,9 @@ if os.path.exists(f):
         "render_bytes_per_launch": emit["hbm_bytes_raw"] + res["hbm_bytes_raw"],
         "render_split": {"raster_emit_kernel": emit["hbm_bytes_raw"], "resolve_write_kernel": res["hbm_bytes_raw"]},
         "batch": 64,
-        "kernels": ["decode_ring_kernel<13,2,8,2,16,64,4,true>", "raster_emit_kernel", "resolve_write_kernel<256>"],
+        "kernels": ["decode_ring_kernel<13,2,8,2,16,64,4,true,NoProbe,true>", "raster_emit_kernel<NoEmitProbe>", "resolve_write_kernel<256>"],
     }, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
-for extra in ("kernel_timing.log",):
+for extra in ("kernel_timing.log", "decode_breakdown.json", "decode_ab.json", "emit_phase_account.json", "bwd_probe.log"):
     f = os.path.join(src, extra)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s" % (tag, extra)))
