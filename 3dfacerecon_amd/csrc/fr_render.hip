@@ -487,9 +487,8 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     PR pr;
     pr.begin();
     __shared__ uint32_t cnt[OFF_STRIDE];  // per-bucket record count; turned into the bucket's start offset in phase C
-    __shared__ uint32_t wq[EMIT_BLOCK / 64];  // per wave: survivors queued in the wave's own region of the queue -- low half
-                                              // = single-pixel ones (from the region's first slot up), high half = multi-pixel
-                                              // ones (from its last slot down)
+    __shared__ unsigned long long qn2;  // survivors queued: low word = single-pixel ones (from slot 0 up), high word =
+                                        // multi-pixel ones (from slot SEG-1 down)
     __shared__ float4 qa[SEG];   // phase A->B: x1 y1 x2 y2          phase B->C: the record
     __shared__ float4 qb[SEG];   // phase A->B: x3 y3 z1 z2          phase B->C: the record's normal
     __shared__ uint2 qd[SEG];    // .x: z3 (raw bits) in A->B, then bucket << 16 | pos (~0 = none) in B->C; .y: local index
@@ -498,9 +497,9 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     const int b = a.nseg_magic ? (int)__umulhi((uint32_t)lid, a.nseg_magic) : lid / a.nseg;  // lid / nseg
     const int seg = lid - b * a.nseg;
     const int S = a.strips;
-    // (no barrier here: the bucket counters are first touched in phase B, behind the barrier that ends phase A, and the
-    // survivor queue is not allocated with an atomic on a shared counter any more -- every wave fills its OWN region)
     if (tid < 2 * S) cnt[tid] = 0;
+    if (tid == 0) qn2 = 0ull;
+    __syncthreads();
     pr.template stamp<0>();
 
     const int nver = a.nver, ntri = a.ntri;
@@ -571,27 +570,30 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             }
         }
         pr.template stamp<1>();   // gathers back, bbox + pre-cull done
-        // Survivors of both triangles are compacted into a two-ended queue: bboxes holding a single pixel centre (~78 % on
-        // the BFM-scale mesh) fill it from the front, the others from the back.  Phase B's waves are then (nearly)
-        // homogeneous: the pixel loop of a wave runs as long as its LONGEST lane, and mixing one 2- or 4-pixel triangle into
-        // a wave of 1-pixel ones doubles that wave's fp64 work.  Every wave owns the region [128 w, 128 w + its triangle
-        // count) of the queue -- it can hold all of the wave's triangles -- so a slot is the wave-local rank: no atomic, no
-        // shared counter that would have to be zeroed behind a barrier of its own.
-        static_assert(TPT == 2 && EMIT_ACTIVE <= EMIT_BLOCK && SEG <= 2 * EMIT_BLOCK, "compaction below: two triangles per thread");
+        // Survivors of both triangles are compacted with ONE LDS atomic per wave, into a two-ended queue: bboxes holding a
+        // single pixel centre (~78 % on the BFM-scale mesh) fill it from the front, the others from the back.  Phase B's
+        // waves are then (nearly) homogeneous: the pixel loop of a wave runs as long as its LONGEST lane, and mixing one
+        // 2- or 4-pixel triangle into a wave of 1-pixel ones doubles that wave's fp64 work.
+        // (Round 3, measured and not kept: per-wave queue regions filled by wave-local ranks -- no allocation atomic, no
+        // zero-init barrier at kernel entry: 12.4 k vs 12.2 k cycles of wave life in the stamped build, and 45-46 vs 42.5-44 us
+        // for the kernel in three bench sessions each.)
+        static_assert(TPT == 2, "compaction below is written for two triangles per thread");
         const unsigned long long ms0 = __ballot(surv[0] && single[0]), ms1 = __ballot(surv[1] && single[1]);
         const unsigned long long mm0 = __ballot(surv[0] && !single[0]), mm1 = __ballot(surv[1] && !single[1]);
         const uint32_t cs0 = (uint32_t)__popcll(ms0), cs1 = (uint32_t)__popcll(ms1);
         const uint32_t cm0 = (uint32_t)__popcll(mm0), cm1 = (uint32_t)__popcll(mm1);
-        const int wave = tid >> 6;
-        const uint32_t rbase = 128u * (uint32_t)wave;                                    // first slot of the wave's region
-        const uint32_t rlast = min((uint32_t)SEG, rbase + 128u) - 1u;                    // its last slot
-        if ((tid & 63) == 0) wq[wave] = ((cm0 + cm1) << 16) | (cs0 + cs1);
+        unsigned long long wb = 0;
+        if ((tid & 63) == 0 && (cs0 + cs1 + cm0 + cm1))
+            wb = atomicAdd(&qn2, ((unsigned long long)(cm0 + cm1) << 32) | (unsigned long long)(cs0 + cs1));
+        const uint32_t fbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wb);
+        const uint32_t bbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wb >> 32));
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
             if (surv[u]) {
                 const unsigned long long m = single[u] ? (u ? ms1 : ms0) : (u ? mm1 : mm0);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                const uint32_t slot = single[u] ? rbase + (u ? cs0 : 0u) + rank : rlast - ((u ? cm0 : 0u) + rank);
+                const uint32_t slot = single[u] ? fbase + (u ? cs0 : 0u) + rank
+                                                : (uint32_t)(SEG - 1) - (bbase + (u ? cm0 : 0u) + rank);
                 qa[slot] = make_float4(x1[u], y1[u], x2[u], y2[u]);
                 qb[slot] = make_float4(x3[u], y3[u], z1[u], z2[u]);
                 qd[slot] = make_uint2(__float_as_uint(z3[u]), (uint32_t)(u * EMIT_ACTIVE + tid));
@@ -603,21 +605,10 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     pr.template stamp<3>();
 
     // ---------------- phase B: dense lanes, one surviving triangle each ----------------
-    // the dense list: the four waves' single-pixel survivors, then their multi-pixel ones (queue_slot maps list index -> slot)
-    const uint32_t w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
-    const int f1 = (int)(w0 & 0xFFFFu), f2 = f1 + (int)(w1 & 0xFFFFu), f3 = f2 + (int)(w2 & 0xFFFFu),
-              nqf = f3 + (int)(w3 & 0xFFFFu);
-    const int m1 = nqf + (int)(w0 >> 16), m2 = m1 + (int)(w1 >> 16), m3 = m2 + (int)(w2 >> 16), nq = m3 + (int)(w3 >> 16);
-    auto queue_slot = [&](int qi) -> int {
-        if (qi < nqf) {  // front of wave w's region
-            const int w = (qi >= f1) + (qi >= f2) + (qi >= f3);
-            return 128 * w + (qi - (w == 0 ? 0 : w == 1 ? f1 : w == 2 ? f2 : f3));
-        }
-        const int w = (qi >= m1) + (qi >= m2) + (qi >= m3);
-        return min(SEG, 128 * w + 128) - 1 - (qi - (w == 0 ? nqf : w == 1 ? m1 : w == 2 ? m2 : m3));
-    };
+    const unsigned long long q2 = qn2;
+    const int nqf = (int)(uint32_t)q2, nq = nqf + (int)(uint32_t)(q2 >> 32);
     for (int qi = tid; qi < nq; qi += EMIT_BLOCK) {
-        const int sl = queue_slot(qi);
+        const int sl = qi < nqf ? qi : SEG - 1 - (qi - nqf);  // front part, then the back part (densely packed lanes)
         const float4 A4 = qa[sl], B4 = qb[sl];
         const uint2 D2 = qd[sl];
         const float x1 = A4.x, y1 = A4.y, x2 = A4.z, y2 = A4.w, x3 = B4.x, y3 = B4.y;
@@ -755,7 +746,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     uint4* R = a.recs + ((size_t)b * a.nseg + seg) * SEG;
     float4* Rn = a.recn + ((size_t)b * a.nseg + seg) * SEG;
     for (int qi = tid; qi < nq; qi += EMIT_BLOCK) {
-        const int sl = queue_slot(qi);
+        const int sl = qi < nqf ? qi : SEG - 1 - (qi - nqf);
         const uint32_t tag = qd[sl].x;
         if (tag != 0xFFFFFFFFu) {
             const float4 r = qa[sl];

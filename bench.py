@@ -166,7 +166,8 @@ def parity_gate(plan, net, assets, params_np, H, W, n_faces):
             if not np.array_equal(g[b], w[b], equal_nan=True):
                 bad_planes += 1
     R = O.rotation_matrix_batch(params_np[:n, :3])
-    Vo = O.decode_3dmm(params_np[:n], assets["mu"], assets["pc_shape"], assets["pc_exp"], float(H), R=R)
+    # (the oracle of the arithmetic the plan was built with: the f32 chain, or the opt-in Q30 specification)
+    Vo = O.decode_3dmm(params_np[:n], assets["mu"], assets["pc_shape"], assets["pc_exp"], float(H), R=R, q30=bool(plan.q30))
     Vr = net.vertices_transform(plan.params[:n], R=torch.as_tensor(R, device=plan.device))
     torch.cuda.synchronize(plan.device)
     bad_decode = int(sum(not np.array_equal(Vr[b].cpu().numpy(), Vo[b]) for b in range(n)))
