@@ -68,12 +68,11 @@ def main():
         med = lambda xs: sorted(xs)[len(xs) // 2]  # noqa: E731
         return [round(1e3 * med([e[i].elapsed_time(e[i + 1]) for e in ev[3:]]), 1) for i in range(3)]
 
-    for env in ({}, {"FR_RESOLVE_NT": "1"}, {"FR_DECODE_NT": "1"}, {"FR_RESOLVE_NT": "1", "FR_DECODE_NT": "1"}):
-        for k in ("FR_RESOLVE_NT", "FR_DECODE_NT"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        w = [wall() for _ in range(3)]
-        print("env %s: step wall us %s, decode/emit/resolve (events) %s" % (env, [round(x, 1) for x in w], phases()), flush=True)
+    host = pkg("_lib")   # (fr_set_option; the non-temporal plane stores of round 2's FR_RESOLVE_NT experiment are gone)
+    for env in ({}, {"FR_DECODE_NT": 0}, {}):
+        with host.options(**env):
+            w = [wall() for _ in range(3)]
+            print("knobs %s: step wall us %s, decode/emit/resolve (events) %s" % (env, [round(x, 1) for x in w], phases()), flush=True)
 
 
 if __name__ == "__main__":

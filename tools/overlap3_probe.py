@@ -80,8 +80,8 @@ def main():
                 ev_emit[k % 2].record(s2)
                 p.render_phase(2)
 
-    for waves in ("16", "8"):
-        os.environ["FR_DECODE_WAVES"] = waves
+    for waves in (16, 8):
+        pkg("_lib").set_option("FR_DECODE_WAVES", waves)
         for _ in range(2):
             r = {"decode_alone": wall(dec_alone), "render_alone": wall(ren_alone), "sequential": wall(sequential),
                  "two_streams_independent": wall(both_independent), "pipelined_dependent": wall(pipelined)}

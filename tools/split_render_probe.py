@@ -29,6 +29,7 @@ def main():
     torch.cuda.synchronize()
     h, L = plan._h, plan._L
     p = h.ptr
+    vdense = plan.vertex_proj.contiguous()   # (the plan hands the vertices over in pitched rows; this probe calls the dense op)
     halves = []
     nh = int(os.environ.get("SPLIT", "2"))
     per = B // nh
@@ -37,7 +38,7 @@ def main():
         b0 = i * per
         ws_bytes = L.fr_render_depth_workspace_bytes(per, plan.N, plan.T, S, S)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        args = (p(plan.vertex_proj[b0:b0 + per]), p(net.tri), p(plan.texture), per, plan.N, plan.T, S, S, 3, 1,
+        args = (p(vdense[b0:b0 + per]), p(net.tri), p(plan.texture), per, plan.N, plan.T, S, S, 3, 1,
                 p(outs[0][b0:b0 + per]), p(outs[1][b0:b0 + per]), p(outs[2][b0:b0 + per]), p(outs[3][b0:b0 + per]), p(ws), ws_bytes)
         rc = L.fr_render_depth_forward_phases(*args, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), 4)
         assert rc == 0
