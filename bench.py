@@ -274,10 +274,10 @@ def main():
     # Per-kernel durations are taken live, inside the timed regions, with HIP events on the launch stream -- on every
     # EV_EVERY-th step only: an event pair costs a few microseconds of stream bubble, which at ~130 us per step would
     # otherwise tax every step by ~7 %.
-    EV_EVERY = 8
+    EV_EVERY, EV_FIRST = 10, 5   # steps 5, 15, 25, ...: never the block's first step (it starts on an idle chip)
     # (events for every block are created up front and the per-block max over ranks is taken after the last block, so
     # that the host does nothing but barrier + synchronize + clock reads between two timed regions)
-    evs = [{k: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for k in range(0, K, EV_EVERY)} for _ in range(R)]
+    evs = [{k: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for k in range(min(EV_FIRST, K - 1), K, EV_EVERY)} for _ in range(R)]
     local, ev_all = [], []
     for r in range(R):
         ev = evs[r]
@@ -287,8 +287,7 @@ def main():
         for k in range(K):
             e = ev.get(k)
             if e is None:
-                plan.decode()
-                plan.render()
+                plan.step()   # fr_decode_render_forward: one C call, three launches
             else:  # same three kernels, each bracketed by events (the render op launched phase by phase)
                 e[0].record()
                 plan.decode()
