@@ -784,6 +784,36 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     return base + inc - v;
 }
 
+// The same for TWO values per thread at once (one pass of shuffles over a packed 64-bit word, ONE LDS hop, one pair of
+// barriers instead of two): exclusive prefixes and totals of va and vb, each total < 2^32.
+template <int BLOCK>
+__device__ __forceinline__ void block_exclusive_scan2(uint32_t va, uint32_t vb, unsigned long long* wtot2, uint32_t& exa,
+                                                      uint32_t& exb, uint32_t& tota, uint32_t& totb) {
+    constexpr int NW = BLOCK / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = ((unsigned long long)vb << 32) | va;   // (the halves cannot carry into each other: totals < 2^32)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long n = __shfl_up(inc, d);
+        if (lane >= d) inc += n;
+    }
+    if (lane == 63) wtot2[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const unsigned long long x = wtot2[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    const unsigned long long ex = base + inc - (((unsigned long long)vb << 32) | va);
+    exa = (uint32_t)ex;
+    exb = (uint32_t)(ex >> 32);
+    tota = (uint32_t)tot;
+    totb = (uint32_t)(tot >> 32);
+}
+
 // bits of the 8x4 window mask (bit = dy*8 + dx) whose row dy is < n
 __device__ __forceinline__ uint32_t window_rows_below(int n) {
     return n >= SMALL_H ? 0xFFFFFFFFu : (n <= 0 ? 0u : (1u << (8 * n)) - 1u);
@@ -797,8 +827,10 @@ constexpr size_t resolve_scratch_bytes(int block) {
 // The bin's records are spread over the face's segments (a few per segment).  Walking segments one after the other
 // would serialise ~4 dependent memory round trips per segment; instead the per-segment counts are prefix-summed in
 // LDS and the threads take records from the flattened list, so all record loads of a bin are in flight together.
-template <int BLOCK, bool FUSED = false>
+template <int BLOCK, bool FUSED = false, class PR = NoEmitProbe>
 __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
+    PR pr;
+    pr.begin();
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
     const int tid = threadIdx.x;
     const int bin = xcd_remap(blockIdx.x, gridDim.x);
@@ -843,9 +875,9 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                     lo = off[s > 0 ? 2 * s - 1 : 0];               // start of bucket 2s (s = 0: of bucket 1, past the big ones)
                     hi = off[min(2 * s + 2, 2 * a.strips - 1)];  // end of the boundary bucket below (last strip: of its own)
                 }
-                uint32_t tot_s, tot_b;
-                const uint32_t ex_s = block_exclusive_scan<BLOCK>(hi - lo, wtot, tot_s);
-                const uint32_t ex_b = block_exclusive_scan<BLOCK>(nbig, wtot, tot_b);
+                if (pass == 0 && c0 == 0) pr.template stamp<0>();   // offsets back
+                uint32_t tot_s, tot_b, ex_s, ex_b;
+                block_exclusive_scan2<BLOCK>(hi - lo, nbig, reinterpret_cast<unsigned long long*>(wtot), ex_s, ex_b, tot_s, tot_b);
                 pref[tid] = ex_s;
                 prefb[tid] = ex_b;
                 lo16[tid] = (uint16_t)lo;
@@ -856,9 +888,14 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                 // the flattened list itself: segment `seg` owns entries [ex_s, ex_s + hi - lo) -- a handful each -- and
                 // writes their record slots, so that both passes find record j with ONE LDS read instead of a
                 // log2(BLOCK)-step search through the prefix sums
+                // (Round 3, measured and reverted: the lanes of a wave filling the ranges of the wave's non-empty segments
+                // together -- ballot, readlane, strided fill -- instead of every segment's own thread: this phase 6.3 k ->
+                // 12.2 k cycles.  A strip's records are spread over MANY segments with a few entries each, not a few
+                // segments with many.)
                 if (tot_s <= (uint32_t)SLOT_CAP)
                     for (uint32_t i = 0; i < hi - lo; i++) slotlist[ex_s + i] = (uint32_t)tid * SEG + lo + i;
                 __syncthreads();  // also orders the key initialisation before the first atomics
+                if (pass == 0 && c0 == 0) pr.template stamp<1>();   // scans + slot list done
             }
             // ---- this strip's small records (own bucket + the two boundary buckets) ----
             const uint32_t total = pref[BLOCK];
@@ -884,6 +921,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                         nv[u] = Nbase[slot];
                     }
                 }
+                pr.template stamp<2>();   // (issue of the record + normal loads)
                 uint32_t msk[RF];
                 int p0s[RF];
 #pragma unroll
@@ -900,7 +938,9 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                         atomicMax(keys + (p0s[u] + (bit >> 3) * W + (bit & 7)), key);
                     }
                 }
+                pr.template stamp<3>();   // records back, LDS max done
                 __syncthreads();
+                pr.template stamp<4>();
 #pragma unroll
                 for (int u = 0; u < RF; u++) {
                     const unsigned long long key = ((unsigned long long)r[u].y << 32) | r[u].x;
@@ -992,10 +1032,12 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
             __syncthreads();
         }
     }
+    pr.template stamp<5>();   // winners' normals stored
     if (FUSED)
         write_strip_fused<BLOCK>(a, b, r0, npix, keys);
     else
         write_strip<BLOCK, true>(a, b, r0, npix, keys, vx, vy, vz);
+    pr.finish(0);
 }
 
 // ---- backward: zeros + scatter-add of g/3 to the z row (render_depth_op.cc:345-363) -------------------------

@@ -62,6 +62,37 @@ def test_validation_codes_without_gpu():
     assert L.fr_render_depth_forward(one, one, one, 1, 3, 1, 4, 4, 3, 1, one, one, one, one, nul, 0, nul) == -2
 
 
+def test_round3_entry_points_validate_before_any_hip_call():
+    """fr_decode_render_forward, the Q30 entry points and the packed decode backward return the documented codes for bad
+    arguments without touching the GPU (no device in this container)."""
+    L = pkg("_lib").lib()
+    nul, one = ctypes.c_void_p(0), ctypes.c_void_p(128)
+    f = ctypes.c_float(200.0)
+    # sizes
+    assert L.fr_decode_render_vertex_pitch(53215) == 53216 and L.fr_decode_render_vertex_pitch(64) == 64
+    assert L.fr_decode_render_vertex_pitch(0) == 0 and L.fr_decode_render_vertex_bytes(64, 53215) == 64 * 3 * 53216 * 4
+    args = lambda phases, hand=one, hbytes=3 * 32 * 4, B=1: (one, one, nul, one, one, B, 20, 2, 2, 5, 8, 8, 1, f, hand, hbytes,  # noqa: E731
+                                                             one, one, one, one, nul, 0, nul, phases)
+    assert L.fr_decode_render_forward(*args(0)) == -1 and L.fr_decode_render_forward(*args(16)) == -1      # phase bits
+    assert L.fr_decode_render_forward(*args(11, B=0)) == 0                                                  # empty batch
+    assert L.fr_decode_render_forward(*args(11, hand=nul)) == -2                                            # no hand-off buffer
+    assert L.fr_decode_render_forward(*args(11, hbytes=16)) == -2                                           # too small
+    assert L.fr_decode_render_forward(*args(11, hand=ctypes.c_void_p(16))) == -2                            # not 128-byte aligned
+    a = list(args(11)); a[12] = 3                                                                           # tex_batch neither 1 nor B
+    assert L.fr_decode_render_forward(*a) == -1
+    # Q30: unsupported shape, missing workspace
+    assert L.fr_decode_q30_pack(one, one, one, 10, 600, 10, ctypes.c_void_p(256), 1 << 20, nul) == -4
+    assert L.fr_decode_3dmm_q30(one, ctypes.c_void_p(256), nul, 1, 10, 5, 3, f, one, nul, 0, nul) == -2
+    assert L.fr_decode_3dmm_q30(one, ctypes.c_void_p(256), nul, 1, 10, 600, 3, f, one, one, 1 << 20, nul) == -4
+    assert L.fr_decode_3dmm_q30(one, ctypes.c_void_p(256), nul, 0, 10, 5, 3, f, one, nul, 0, nul) == 0
+    # packed backward: image size = row blocks x coefficient blocks x 1 KiB; too small a buffer; null image
+    rb, sb = (3 * 53215 + 15) // 16, 13 + 2
+    assert L.fr_decode_backward_basis_bytes(53215, 199, 29) == rb * sb * 1024
+    assert L.fr_decode_backward_pack_basis(one, one, 53215, 199, 29, one, 1024, nul) == -2
+    assert L.fr_decode_3dmm_backward_packed(one, one, one, nul, nul, 2, 10, 5, 3, f, one, one, 1 << 30, nul) == -1
+    assert L.fr_decode_3dmm_backward_packed(one, one, one, one, nul, 2, 10, 5, 3, f, one, one, 16, nul) == -2
+
+
 def test_options_read_the_environment_once_and_never_on_the_launch_path(monkeypatch):
     """The launcher knobs take their initial value from the environment ONCE per process; afterwards only fr_set_option
     changes them -- a later change of os.environ (putenv) must not change behaviour, and no kernel source calls getenv

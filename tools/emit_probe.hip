@@ -19,7 +19,11 @@ __device__ __forceinline__ unsigned long long estamp() {
 }
 struct EmitStampProbe {
     unsigned long long t[8];
-    __device__ __forceinline__ void begin() { t[0] = estamp(); }
+    __device__ __forceinline__ void begin() {
+#pragma unroll
+        for (int i = 1; i < 8; i++) t[i] = 0;
+        t[0] = estamp();
+    }
     template <int ID> __device__ __forceinline__ void stamp() { t[ID + 1] = estamp(); }
     __device__ __forceinline__ void finish(int nq) {
         const unsigned long long te = estamp();
@@ -32,6 +36,25 @@ struct EmitStampProbe {
         }
     }
 };
+
+// the same for resolve_write_kernel<256>: stamps [bins][4 waves][10]
+extern "C" int fr_probe_resolve_stamps(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
+                                       int H, int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
+                                       void* workspace, size_t ws_bytes, long long vpitch, unsigned long long* stamps,
+                                       void* hip_stream) {
+    using namespace fr;
+    RenderArgs a;
+    RenderGeom g;
+    bool binned = false;
+    int rc = prepare_render(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr, nullptr,
+                            nullptr, workspace, ws_bytes, vpitch, a, g, &binned);
+    if (rc != FR_OK || !binned || g.lds > 32 * 1024) return rc ? rc : -100;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_emit_stamps), &stamps, sizeof(stamps));
+    const long long nbins = (long long)B * g.strips;
+    hipLaunchKernelGGL((resolve_write_kernel<256, false, EmitStampProbe>), dim3((unsigned)nbins), dim3(256),
+                       g.lds + resolve_scratch_bytes(256), (hipStream_t)hip_stream, a);
+    return hipGetLastError() == hipSuccess ? (int)nbins : FR_ERR_LAUNCH;
+}
 
 extern "C" int fr_probe_emit_stamps(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                                     int H, int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,

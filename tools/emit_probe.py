@@ -95,6 +95,34 @@ def main():
         # phase B by wave index (the queue is dense: waves 2-3 usually have nothing to do)
         rep["phase_B_cycles_median_by_wave"] = [float(np.median(seg[:, w, 4])) for w in range(4)]
         out["stamps"] = rep
+        # ---- the resolver, same method --------------------------------------------------------------------------------
+        P.fr_probe_resolve_stamps.argtypes = P.fr_probe_emit_stamps.argtypes
+        P.fr_probe_resolve_stamps.restype = i
+        for _ in range(20):
+            plan.step()
+        plan.render_phase(1)
+        torch.cuda.synchronize()
+        stamps.zero_()
+        nb = P.fr_probe_resolve_stamps(p(plan._vertex), p(net.tri), p(plan.texture), B, plan.N, plan.T, S, S, plan.tex_batch,
+                                       p(plan.depth), p(plan.texture_image), p(plan.normal), p(plan.tri_ind), p(plan._ws),
+                                       plan._ws_bytes, plan.pitch, p(stamps),
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert nb > 0, nb
+        assert all(torch.equal(a, b) for a, b in zip(plan.outputs(), ref)), "stamped resolver changed the planes"
+        st = stamps.cpu().numpy().reshape(-1, 4, 10)[:nb].astype(np.float64)
+        t = st[:, :, :9]
+        # stamps: 0 entry, 1 offsets back, 2 scans + slot list, 3 record loads issued, 4 records back + LDS max, 5 barrier,
+        # 6 winners' normals stored, 7 unused (= 0 on the fast path), 8 end (plane stores issued)
+        fast = t[:, 0, 4] > 0          # bins that took the single-trip register path
+        names = [("entry -> offsets back (keys initialised meanwhile)", 0, 1), ("two block scans + slot list + barrier", 1, 2),
+                 ("slot list read, record + normal loads issued", 2, 3), ("records back, LDS max", 3, 4), ("barrier", 4, 5),
+                 ("winners' normals stored", 5, 6), ("plane writer: keys -> texture-mean gathers -> stores issued", 6, 8)]
+        rr = {"bins": int(nb), "bins_on_the_single_trip_path": int(fast.sum()), "segments_cycles_median_over_waves": {},
+              "wave_life_cycles_median": float(np.median(t[fast][:, :, 8] - t[fast][:, :, 0]))}
+        for nm, i0, i1 in names:
+            rr["segments_cycles_median_over_waves"][nm] = float(np.median(t[fast][:, :, i1] - t[fast][:, :, i0]))
+        out["resolve_stamps"] = rr
     print(json.dumps(out, indent=1))
 
 
