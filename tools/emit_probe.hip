@@ -37,6 +37,24 @@ struct EmitStampProbe {
     }
 };
 
+// the PRODUCT emit kernel launched with `extra_lds` bytes of (unused) dynamic LDS: limits the workgroups resident per CU
+// (160 KiB / (20.4 KiB + extra)) -- what a kernel fused with the resolver's larger footprint would run at
+extern "C" int fr_probe_emit_with_extra_lds(const float* vertex, const float* tri, const float* texture, int B, int nver,
+                                            int ntri, int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
+                                            float* tri_ind, void* workspace, size_t ws_bytes, long long vpitch, int extra_lds,
+                                            void* hip_stream) {
+    using namespace fr;
+    RenderArgs a;
+    RenderGeom g;
+    bool binned = false;
+    int rc = prepare_render(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr, nullptr,
+                            nullptr, workspace, ws_bytes, vpitch, a, g, &binned);
+    if (rc != FR_OK || !binned) return rc ? rc : -100;
+    hipLaunchKernelGGL(raster_emit_kernel<NoEmitProbe>, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), (size_t)extra_lds,
+                       (hipStream_t)hip_stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : FR_ERR_LAUNCH;
+}
+
 // the same for resolve_write_kernel<256>: stamps [bins][4 waves][10]
 extern "C" int fr_probe_resolve_stamps(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                                        int H, int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,

@@ -95,6 +95,20 @@ def main():
         # phase B by wave index (the queue is dense: waves 2-3 usually have nothing to do)
         rep["phase_B_cycles_median_by_wave"] = [float(np.median(seg[:, w, 4])) for w in range(4)]
         out["stamps"] = rep
+        # ---- emit at reduced residency (extra, unused dynamic LDS): 8 / 7 / 6 / 5 / 4 workgroups per CU ---------------------
+        P.fr_probe_emit_with_extra_lds.argtypes = [vp, vp, vp, i, i, i, i, i, i, vp, vp, vp, vp, vp, ctypes.c_size_t,
+                                                   ctypes.c_longlong, i, vp]
+        P.fr_probe_emit_with_extra_lds.restype = i
+        occ = {}
+        for wgs, extra in ((8, 0), (7, 2400), (6, 6000), (5, 11000), (4, 19000)):
+            def run():
+                rc = P.fr_probe_emit_with_extra_lds(p(plan._vertex), p(net.tri), p(plan.texture), B, plan.N, plan.T, S, S,
+                                                    plan.tex_batch, p(plan.depth), p(plan.texture_image), p(plan.normal),
+                                                    p(plan.tri_ind), p(plan._ws), plan._ws_bytes, plan.pitch, extra,
+                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                assert rc == 0, rc
+            occ["%d workgroups per CU" % wgs] = round(wall(run), 1)
+        out["emit_alone_us_by_residency"] = occ
         # ---- the resolver, same method --------------------------------------------------------------------------------
         P.fr_probe_resolve_stamps.argtypes = P.fr_probe_emit_stamps.argtypes
         P.fr_probe_resolve_stamps.restype = i
