@@ -41,6 +41,11 @@ def shard_range(total, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def _collective_device(device):
+    """gloo reduces host tensors (the CPU tests, and `bench.py --dist-backend gloo`); RCCL reduces device tensors."""
+    return "cpu" if dist.get_backend() == "gloo" else device
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
@@ -50,7 +55,7 @@ def max_over_ranks(value, device="cpu"):
     """MAX of a python float over all ranks (the bench's step time)."""
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_collective_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -58,7 +63,7 @@ def max_over_ranks(value, device="cpu"):
 def sum_over_ranks(value, device="cpu"):
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_collective_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -67,7 +72,7 @@ def gather_over_ranks(value, device="cpu"):
     """The python float of every rank, in rank order (the bench's per-rank step times)."""
     if not (dist.is_available() and dist.is_initialized()):
         return [float(value)]
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_collective_device(device))
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [float(x.item()) for x in out]

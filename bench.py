@@ -233,6 +233,10 @@ def main():
                     help="faces per rank the oracle checks before the line is printed (-1 = all of them; 0 = skip, the "
                          "line then carries parity = null and must not be quoted)")
     ap.add_argument("--no-ops-surface", action="store_true", help="skip the operator-surface leg")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend for N > 1.  nccl (= RCCL) is the product setting.  gloo exists to walk the "
+                         "N > 1 control flow on a box with fewer GPUs than ranks (ranks then share devices, LOCAL_RANK "
+                         "modulo the device count); the line's dist.backend says gloo, so it cannot pass for an RCCL run")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -242,9 +246,11 @@ def main():
     import numpy as np
     import torch
     dist_u = pkg("utils.dist")
-    world, rank, local = dist_u.init_from_env("nccl" if args.gpus > 1 else None)
+    world, rank, local = dist_u.init_from_env(args.dist_backend if args.gpus > 1 else None)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X; the hot path has no CPU fallback")
+    if args.dist_backend == "gloo":
+        local %= torch.cuda.device_count()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -399,6 +405,7 @@ def main():
             "repeats": R, "value_is": "median over %d timed blocks of K steps each" % R,
             "value_min": faces_per_step * K / max(blocks), "value_max": faces_per_step * K / min(blocks),
             "ms_per_step_min": 1e3 * min(blocks) / K, "ms_per_step_max": 1e3 * max(blocks) / K,
+            "blocks_ms_per_step": [round(1e3 * t / K, 5) for t in blocks],   # every timed block, in the order they ran
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: batch %d random 235-d params -> 3DMM decode -> depth render, "
                                    "%dx%d, fp32, all four output planes" % (args.batch, H, W),

@@ -1,0 +1,62 @@
+"""bench.py run as the driver runs it -- as a program, its ONE JSON line parsed -- on the GPU box.
+
+The N > 1 legs walk the multi-rank control flow (partition, barrier + synchronize brackets, MAX over ranks, the parity gate
+on every rank, the `dist` block) with two ranks that SHARE the one GPU of the test box over gloo: RCCL refuses two ranks on
+one device, so the collective library itself is the one thing these legs cannot cover; the line says `backend: gloo`."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHORT = ["--steps", "3", "--warmup", "1", "--repeats", "2"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _line(cmd):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]          # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_line_one_gpu():
+    d = _line([sys.executable, "bench.py"] + SHORT + ["--cpu-faces", "8"])
+    assert d["metric"].startswith("faces/sec") and d["unit"] == "faces/s" and d["n_gpus"] == 1 and d["steps"] == 3
+    assert d["value"] > 1e4 and abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert d["parity"]["ok"] and d["parity"]["faces"] == 64 and d["parity"]["mismatching_planes"] == 0
+    assert d["ops_surface"]["outputs_identical_to_plan"] and d["ops_surface_faces_per_s"] > 1e4
+    assert d["dist"]["world_size"] == 1 and d["config"]["faces_per_step_all_gpus"] == 64
+
+
+@pytest.mark.parametrize("scaling,global_faces,local_faces", [("weak", 128, 64), ("strong", 64, 32)])
+def test_bench_two_ranks_walk_the_multi_rank_flow(scaling, global_faces, local_faces):
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--dist-backend", "gloo",
+               "--scaling", scaling, "--cpu-faces", "0", "--no-ops-surface"] + SHORT)
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling
+    assert d["dist"]["backend"] == "gloo" and d["dist"]["world_size"] == 2 and d["dist"]["ranks_reporting"] == 2
+    assert len(d["dist"]["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["dist"]["per_rank_ms_per_step"])
+    assert d["config"]["faces_per_step_all_gpus"] == global_faces and d["config"]["faces_per_gpu_rank0"] == local_faces
+    # value is the whole job: all ranks' faces over the slowest rank's time
+    assert abs(d["value"] - global_faces * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert abs(d["ms_per_step"] - max(d["dist"]["per_rank_ms_per_step"])) < 1e-9     # MAX over ranks of the reported block
+    p = d["parity"]
+    assert p["ok"] and p["faces_all_ranks"] == global_faces and p["mismatching_planes_all_ranks"] == 0
+    assert d["cpu_baseline"] is None            # rank 0 at N = 1 only
