@@ -224,7 +224,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="faces per GPU per step")
     ap.add_argument("--im-size", type=int, default=200)
-    ap.add_argument("--repeats", type=int, default=10, help="timed K-step blocks; the median block is reported")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed K-step blocks; the median block is reported.  0 = auto: max(10, 600 // K) -- the first "
+                         "~15 ms of GPU work after the host-side set-up run on a chip that is still ramping its clock "
+                         "(blocks_ms_per_step in the line shows it), so the blocks have to span well beyond that for "
+                         "the median to be a steady-state block")
     ap.add_argument("--cpu-faces", type=int, default=2048, help="faces in the cpu_baseline sample (0 = skip); 2048 ~ 10 s")
     ap.add_argument("--graph", action="store_true", help="also report hipGraph-replay throughput")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -271,7 +275,8 @@ def main():
     plan.params.copy_(torch.as_tensor(params_np, device=dev))
     torch.cuda.synchronize(dev)
 
-    K, Wm, R = args.steps, args.warmup, max(1, args.repeats)
+    K, Wm = args.steps, args.warmup
+    R = args.repeats if args.repeats > 0 else max(10, 600 // max(1, K))
     for _ in range(Wm):
         plan.step()
     # The timed region -- EXACTLY K steps between barrier + synchronize brackets -- is run R times back to back and the
