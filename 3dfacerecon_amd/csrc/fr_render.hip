@@ -47,9 +47,9 @@ struct RenderArgs {
     int strips;            // strips per face
     long long tex_stride;  // 0 (shared texture) or 3*nver
     // binned path workspace
-    uint4* recs;           // [B][nseg][SEG] records
+    uint4* recs;           // [B][nseg][SEG][2] 16-byte records, each followed by its un-normalised normal (xyz as a float4): the
+                           // resolver reads both, so they share a 32-byte half line
     uint16_t* segoff;      // [B][nseg][OFF_STRIDE] bucket offsets
-    float4* recn;          // [B][nseg][SEG] un-normalised normal (xyz) of the record in the same slot of `recs`
     float4* tritex_ws;     // [tex_batch][ntri] per-triangle texture mean (one copy when the texture is shared)
     int nseg;
     // fused rendering-layer outputs (fr_rendering_layer_forward; network.py:185-199 folded into the resolver)
@@ -465,6 +465,19 @@ __device__ __forceinline__ float div3(float x) {
     return x / 3.0f;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave in six v_add_u32_dpp (Hillis-Steele inside each row of 16 lanes, then the
+// row totals passed on with row_bcast:15 / row_bcast:31) -- the __shfl_up form is six DEPENDENT trips through the LDS
+// crossbar (ds_bpermute), several hundred cycles on the critical path of every workgroup of both kernels.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1 (out-of-row lanes read 0)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 // The kernel is VALU-bound (rocprof: SQ_ACTIVE_INST_VALU ~ 94 % of its duration), and about half of all triangles
 // are rejected by the bbox rule before any fp64 work.  So it runs in two phases.  Phase A: every thread takes TPT
 // triangles of the segment (all their loads in flight together), does the ids, the nine gathers and the bbox reject,
@@ -727,15 +740,9 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     // (one wave scans, the other three wait at the barrier: a variant in which every wave scans for itself and reads the
     // bucket base with a cross-lane shuffle -- no third barrier -- measured 2 us SLOWER per launch, A/B in one process)
     uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
-    if (tid < 64) {  // one wave scans the (at most 64) bucket counts
-        const int lane = tid;
+    if (tid < 64) {  // one wave (all 64 lanes active, as the DPP scan needs) scans the (at most 64) bucket counts
         const uint32_t c = (tid < 2 * S) ? cnt[tid] : 0u;
-        uint32_t inc = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t n = __shfl_up(inc, d);
-            if (lane >= d) inc += n;
-        }
+        const uint32_t inc = wave_inclusive_scan(c);
         if (tid < 2 * S) {
             cnt[tid] = inc - c;          // start of bucket k
             off[tid] = (uint16_t)inc;    // end of bucket k (off[0] = #big)
@@ -743,33 +750,27 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     }
     __syncthreads();
     pr.template stamp<6>();
-    uint4* R = a.recs + ((size_t)b * a.nseg + seg) * SEG;
-    float4* Rn = a.recn + ((size_t)b * a.nseg + seg) * SEG;
+    uint4* R = a.recs + ((size_t)b * a.nseg + seg) * (2 * SEG);
     for (int qi = tid; qi < nq; qi += EMIT_BLOCK) {
         const int sl = qi < nqf ? qi : SEG - 1 - (qi - nqf);
         const uint32_t tag = qd[sl].x;
         if (tag != 0xFFFFFFFFu) {
             const float4 r = qa[sl];
             const uint32_t slot = cnt[tag >> 16] + (tag & 0xFFFFu);
-            R[slot] = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
-            Rn[slot] = qb[sl];
+            R[2 * slot] = make_uint4(__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w));
+            *reinterpret_cast<float4*>(R + 2 * slot + 1) = qb[sl];
         }
     }
     pr.finish(nq);
 }
 
 // ---- binned path, kernel 2: per (face, strip) LDS resolve + output ----------------------------------------
-// Block-wide exclusive scan of one value per thread (wave shuffles + one LDS hop).
+// Block-wide exclusive scan of one value per thread (wave scan + one LDS hop).
 template <int BLOCK>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wtot, uint32_t& total) {
     constexpr int NW = BLOCK / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t n = __shfl_up(inc, d);
-        if (lane >= d) inc += n;
-    }
+    const uint32_t inc = wave_inclusive_scan(v);
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();
     uint32_t base = 0, tot = 0;
@@ -791,12 +792,8 @@ __device__ __forceinline__ void block_exclusive_scan2(uint32_t va, uint32_t vb, 
                                                       uint32_t& exb, uint32_t& tota, uint32_t& totb) {
     constexpr int NW = BLOCK / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long inc = ((unsigned long long)vb << 32) | va;   // (the halves cannot carry into each other: totals < 2^32)
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long n = __shfl_up(inc, d);
-        if (lane >= d) inc += n;
-    }
+    // (two wave scans, then ONE packed LDS hop: the halves cannot carry into each other, the totals are < 2^32)
+    const unsigned long long inc = ((unsigned long long)wave_inclusive_scan(vb) << 32) | wave_inclusive_scan(va);
     if (lane == 63) wtot2[wave] = inc;
     __syncthreads();
     unsigned long long base = 0, tot = 0;
@@ -864,8 +861,8 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     const bool one_chunk = a.nseg <= BLOCK;  // the usual case: the offsets and both scans are done once, not per pass
     for (int pass = 0; pass < 2; pass++) {
         for (int c0 = 0; c0 < a.nseg; c0 += BLOCK) {
-            const uint4* Rbase = a.recs + ((size_t)b * a.nseg + c0) * SEG;
-            const float4* Nbase = a.recn + ((size_t)b * a.nseg + c0) * SEG;
+            const uint4* Rbase = a.recs + ((size_t)b * a.nseg + c0) * (2 * SEG);   // record k at [2k], its normal at [2k + 1]
+            const float4* Nbase = reinterpret_cast<const float4*>(Rbase) + 1;
             if (pass == 0 || !one_chunk) {
                 const int seg = c0 + tid;
                 uint32_t nbig = 0, lo = 0, hi = 0;
@@ -917,8 +914,8 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                     nv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (j < total) {
                         const uint32_t slot = slotlist[j];
-                        r[u] = Rbase[slot];
-                        nv[u] = Nbase[slot];
+                        r[u] = Rbase[2 * slot];
+                        nv[u] = Nbase[2 * slot];
                     }
                 }
                 pr.template stamp<2>();   // (issue of the record + normal loads)
@@ -976,7 +973,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                                 if (pref[k + step] <= j) k += step;  // largest k with pref[k] <= j
                             slot[u] = (uint32_t)k * SEG + lo16[k] + (j - pref[k]);
                         }
-                        r[u] = Rbase[slot[u]];
+                        r[u] = Rbase[2 * slot[u]];
                     }
                 }
 #pragma unroll
@@ -1001,7 +998,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                             if (keys[p0 + (bit >> 3) * W + (bit & 7)] == key) won |= 1u << bit;
                         }
                         if (won) {
-                            float4 nv = Nbase[slot[u]];
+                            float4 nv = Nbase[2 * slot[u]];
                             if (FUSED) nv = post_normal(nv);
                             while (won) {
                                 const int bit = __ffs((int)won) - 1;
@@ -1021,13 +1018,13 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                 for (int step = BLOCK >> 1; step > 0; step >>= 1)
                     if (prefb[k + step] <= j) k += step;
                 const uint32_t slot = (uint32_t)k * SEG + (j - prefb[k]);
-                const uint4 r = Rbase[slot];
+                const uint4 r = Rbase[2 * slot];
                 const int t = (int)(0xFFFFFFFFu - r.x);
                 if (pass == 0)
                     raster_triangle_into_strip<false>(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, W, r0, r1, keys);
                 else
                     raster_triangle_into_strip<true>(t, a.tri, vx, vy, vz, a.nver, a.ntri, a.H, W, r0, r1, keys, nplane,
-                                                     FUSED ? post_normal(Nbase[slot]) : Nbase[slot], NSTRIDE);
+                                                     FUSED ? post_normal(Nbase[2 * slot]) : Nbase[2 * slot], NSTRIDE);
             }
             __syncthreads();
         }
@@ -1463,7 +1460,7 @@ static int prepare_render(const float* vertex, const float* tri, const float* te
     a.rows = g.rows; a.strips = g.strips;
     a.tex_stride = (tex_batch == 1) ? 0 : 3ll * nver;
     a.recs = nullptr; a.segoff = nullptr; a.nseg = g.nseg;
-    a.recn = nullptr; a.tritex_ws = nullptr;
+    a.tritex_ws = nullptr;
     a.im_gray = im_gray; a.net_in = net_in; a.depth_img = depth_img;
     a.wm1 = (float)(W - 1);
     a.hm1 = (float)(H - 1);
@@ -1479,9 +1476,8 @@ static int prepare_render(const float* vertex, const float* tri, const float* te
         ((uintptr_t)workspace & 15))
         return FR_ERR_WORKSPACE;
     char* wsp = reinterpret_cast<char*>(workspace);
-    a.recs = reinterpret_cast<uint4*>(wsp);
-    a.segoff = reinterpret_cast<uint16_t*>(wsp + g.recs_bytes);
-    a.recn = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes);
+    a.recs = reinterpret_cast<uint4*>(wsp);   // records interleaved with their normals: recs_bytes + nrm_bytes
+    a.segoff = reinterpret_cast<uint16_t*>(wsp + g.recs_bytes + g.nrm_bytes);
     a.tritex_ws = reinterpret_cast<float4*>(wsp + g.recs_bytes + g.segoff_bytes + g.nrm_bytes);
     a.tri4 = reinterpret_cast<int4*>(wsp + g.recs_bytes + g.segoff_bytes + 2 * g.nrm_bytes);
     // lid / nseg through the 2^32 reciprocal is exact while lid * (magic * nseg - 2^32) < 2^32, i.e. B * nseg^2 < 2^32
