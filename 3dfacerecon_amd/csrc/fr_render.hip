@@ -512,8 +512,8 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     const int S = a.strips;
     if (tid < 2 * S) cnt[tid] = 0;
     if (tid == 0) qn2 = 0ull;
-    __syncthreads();
-    pr.template stamp<0>();
+    // (the barrier that publishes these zeros sits below, behind the issue of phase A's gathers: the waves wait for memory
+    // there anyway, and an LDS-only barrier -- no vmcnt(0) fence -- leaves the gathers in flight)
 
     const int nver = a.nver, ntri = a.ntri;
     const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.vpitch;
@@ -542,6 +542,8 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             y1[u] = ld_boff(vy, e[u].x); y2[u] = ld_boff(vy, e[u].y); y3[u] = ld_boff(vy, e[u].z);
             z1[u] = ld_boff(vz, e[u].x); z2[u] = ld_boff(vz, e[u].y); z3[u] = ld_boff(vz, e[u].z);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // counters zeroed (first used by the compaction below)
+        pr.template stamp<0>();
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
             // bbox = ceil(min) .. floor(max) per axis and the whole-triangle reject of render_depth_op.cc:276-283, in the
