@@ -49,7 +49,8 @@ struct RenderArgs {
     // binned path workspace
     uint4* recs;           // [B][nseg][SEG][2] 16-byte records, each followed by its un-normalised normal (xyz as a float4): the
                            // resolver reads both, so they share a 32-byte half line
-    uint16_t* segoff;      // [B][nseg][OFF_STRIDE] bucket offsets
+    uint16_t* segoff;      // [B][OFF_STRIDE][nseg] bucket offsets, bucket-major: the resolver's thread = segment reads of one bucket
+                           // are one coalesced line (segment-major, every thread touched its own 128-byte line)
     float4* tritex_ws;     // [tex_batch][ntri] per-triangle texture mean (one copy when the texture is shared)
     int nseg;
     // fused rendering-layer outputs (fr_rendering_layer_forward; network.py:185-199 folded into the resolver)
@@ -741,13 +742,13 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
     // ---------------- phase C: bucket offsets, records out ----------------
     // (one wave scans, the other three wait at the barrier: a variant in which every wave scans for itself and reads the
     // bucket base with a cross-lane shuffle -- no third barrier -- measured 2 us SLOWER per launch, A/B in one process)
-    uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
+    uint16_t* off = a.segoff + (size_t)b * OFF_STRIDE * a.nseg + seg;   // bucket k of this segment at off[k * nseg]
     if (tid < 64) {  // one wave (all 64 lanes active, as the DPP scan needs) scans the (at most 64) bucket counts
         const uint32_t c = (tid < 2 * S) ? cnt[tid] : 0u;
         const uint32_t inc = wave_inclusive_scan(c);
         if (tid < 2 * S) {
             cnt[tid] = inc - c;          // start of bucket k
-            off[tid] = (uint16_t)inc;    // end of bucket k (off[0] = #big)
+            off[(size_t)tid * a.nseg] = (uint16_t)inc;    // end of bucket k (bucket 0: #big)
         }
     }
     __syncthreads();
@@ -869,10 +870,10 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
                 const int seg = c0 + tid;
                 uint32_t nbig = 0, lo = 0, hi = 0;
                 if (seg < a.nseg) {
-                    const uint16_t* off = a.segoff + ((size_t)b * a.nseg + seg) * OFF_STRIDE;
+                    const uint16_t* off = a.segoff + (size_t)b * OFF_STRIDE * a.nseg + seg;
                     nbig = off[0];
-                    lo = off[s > 0 ? 2 * s - 1 : 0];               // start of bucket 2s (s = 0: of bucket 1, past the big ones)
-                    hi = off[min(2 * s + 2, 2 * a.strips - 1)];  // end of the boundary bucket below (last strip: of its own)
+                    lo = off[(size_t)(s > 0 ? 2 * s - 1 : 0) * a.nseg];               // start of bucket 2s (s = 0: of bucket 1, past the big ones)
+                    hi = off[(size_t)min(2 * s + 2, 2 * a.strips - 1) * a.nseg];  // end of the boundary bucket below (last strip: of its own)
                 }
                 if (pass == 0 && c0 == 0) pr.template stamp<0>();   // offsets back
                 uint32_t tot_s, tot_b, ex_s, ex_b;
