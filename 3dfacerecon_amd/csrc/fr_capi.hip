@@ -14,7 +14,7 @@ struct OptDesc {
 };
 const OptDesc kOpts[fr::OPT_COUNT] = {
     {"FR_DECODE_IMPL", 0, "loop"}, {"FR_DECODE_WIDE", 1, nullptr}, {"FR_DECODE_NBW", 0, nullptr},
-    {"FR_DECODE_WAVES", 16, nullptr}, {"FR_DECODE_NT", 1, nullptr}, {"FR_RESOLVE_OPT", 1, nullptr},
+    {"FR_DECODE_WAVES", 16, nullptr}, {"FR_DECODE_NT", 1, nullptr}, {"FR_RESOLVE_OPT", 2, nullptr},
     {"FR_EMIT_FILTER", 3, nullptr}, {"FR_RENDER_IMPL", 0, "scan"}, {"FR_RESOLVE_BLOCK", 0, nullptr},
     {"FR_RENDER_ROWS", 0, nullptr},
 };

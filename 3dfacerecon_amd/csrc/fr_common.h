@@ -100,7 +100,8 @@ enum Opt {
     OPT_DECODE_NBW,     // FR_DECODE_NBW     0 = auto, 1 / 4 = column blocks per work item
     OPT_DECODE_WAVES,   // FR_DECODE_WAVES   16 (default) or 8 waves per decode workgroup
     OPT_DECODE_NT,      // FR_DECODE_NT      1 = non-temporal basis stream (default), 0 = default cache policy
-    OPT_RESOLVE_OPT,    // FR_RESOLVE_OPT    1 = single-trip bins keep records in registers (default), 0 = two-pass resolver
+    OPT_RESOLVE_OPT,    // FR_RESOLVE_OPT    2 = wave-local front for 256-thread bins (default), 1 = single-trip bins keep records in
+                        //                   registers behind the block-wide list, 0 = two-pass resolver
     OPT_EMIT_FILTER,    // FR_EMIT_FILTER    bit 0: certified fp32 inside test, bit 1: single-pixel pre-cull (default 3)
     OPT_RENDER_IMPL,    // FR_RENDER_IMPL    0 = binned rasteriser (default), 1 ("scan") = strip-scan fallback
     OPT_RESOLVE_BLOCK,  // FR_RESOLVE_BLOCK  0 = auto, 256 / 512 / 1024 threads per resolver workgroup

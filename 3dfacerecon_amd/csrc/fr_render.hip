@@ -862,6 +862,139 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     // pixels up again and, where its key won, stores its normal (kept in the record's companion slot) to the normal
     // plane.  The second read of the records is an L1/L2 hit.
     const bool one_chunk = a.nseg <= BLOCK;  // the usual case: the offsets and both scans are done once, not per pass
+    // ---- wave-local front (FR_RESOLVE_OPT=2, 256-thread bins) -------------------------------------------------------------
+    // The general front below flattens the bin's records into ONE list for the workgroup: a block scan (two barriers), the
+    // list (a third), then the loads.  Here every wave flattens the records of ITS segments (dealt round-robin, so the four
+    // waves own equal shares) with a DPP scan into its own quarter of the slot list -- no barrier, LDS is in order inside
+    // a wave -- and issues its loads at once; the ONE barrier that follows (LDS-only: the loads stay in flight) publishes
+    // the initialised keys and each wave's verdict.  The first six records per lane stay in registers (with their normals)
+    // for the second pass; what a busy wave has beyond that goes through a short reload loop.  A wave whose share does not
+    // fit its quarter of the list, or that saw a big record, says so and the whole bin takes the general path (the
+    // speculative loads are dropped).
+    if constexpr (BLOCK == 256) {
+        if (one_chunk && a.resolve_opt == 2) {
+            constexpr int NW = BLOCK / 64, RF = 6, WCAP = SLOT_CAP / NW;
+            static_assert(64 * RF <= WCAP, "a wave's share of the slot list");
+            const int lane = tid & 63, wave = tid >> 6;
+            const int seg = lane * NW + wave;
+            const uint4* Rbase = a.recs + (size_t)b * a.nseg * (2 * SEG);
+            const float4* Nbase = reinterpret_cast<const float4*>(Rbase) + 1;
+            uint32_t nbig = 0, lo = 0, hi = 0;
+            if (seg < a.nseg) {
+                const uint16_t* off = a.segoff + (size_t)b * OFF_STRIDE * a.nseg + seg;
+                nbig = off[0];
+                lo = off[(size_t)(s > 0 ? 2 * s - 1 : 0) * a.nseg];
+                hi = off[(size_t)min(2 * s + 2, 2 * a.strips - 1) * a.nseg];
+            }
+            pr.template stamp<0>();   // offsets back
+            const uint32_t cntw = hi - lo, inc = wave_inclusive_scan(cntw), ex = inc - cntw;
+            const uint32_t total_w = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            const bool ok_w = total_w <= (uint32_t)WCAP && __ballot(nbig != 0) == 0ull;
+            uint32_t* wl = slotlist + wave * WCAP;
+            uint32_t* wstat = wtot + 48;
+            if (lane == 0) wstat[wave] = ok_w ? 1u : 0u;
+            uint4 r[RF];
+            float4 nv[RF];
+            if (ok_w) {
+                for (uint32_t i = 0; i < cntw; i++) wl[ex + i] = (uint32_t)seg * SEG + lo + i;
+                pr.template stamp<1>();   // wave list done
+#pragma unroll
+                for (int u = 0; u < RF; u++) {
+                    const uint32_t j = lane + u * 64;
+                    r[u] = make_uint4(0, 0, 0, 0);
+                    nv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j < total_w) {
+                        const uint32_t slot = wl[j];
+                        r[u] = Rbase[2 * slot];
+                        nv[u] = Nbase[2 * slot];
+                    }
+                }
+                pr.template stamp<2>();   // (issue of the record + normal loads)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // keys initialised, verdicts published
+            bool all_ok = true;
+#pragma unroll
+            for (int w = 0; w < NW; w++) all_ok = all_ok && wstat[w] != 0;
+            if (all_ok) {
+                uint32_t msk[RF];
+                int p0s[RF];
+#pragma unroll
+                for (int u = 0; u < RF; u++) {
+                    const unsigned long long key = ((unsigned long long)r[u].y << 32) | r[u].x;
+                    const int x0 = (int)(r[u].z & 0xFFFFu), y0 = (int)(r[u].z >> 16);
+                    p0s[u] = (y0 - r0) * W + x0;
+                    uint32_t m = r[u].w;
+                    m &= window_rows_below(r1 - y0) & ~window_rows_below(r0 - y0);
+                    msk[u] = m;
+                    while (m) {
+                        const int bit = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        atomicMax(keys + (p0s[u] + (bit >> 3) * W + (bit & 7)), key);
+                    }
+                }
+                for (uint32_t j = 64 * RF + lane; j < total_w; j += 64) {   // the wave's records beyond six per lane
+                    const uint4 rr = Rbase[2 * wl[j]];
+                    const unsigned long long key = ((unsigned long long)rr.y << 32) | rr.x;
+                    const int x0 = (int)(rr.z & 0xFFFFu), y0 = (int)(rr.z >> 16);
+                    const int p0 = (y0 - r0) * W + x0;
+                    uint32_t m = rr.w & window_rows_below(r1 - y0) & ~window_rows_below(r0 - y0);
+                    while (m) {
+                        const int bit = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        atomicMax(keys + (p0 + (bit >> 3) * W + (bit & 7)), key);
+                    }
+                }
+                pr.template stamp<3>();   // records back, LDS max done
+                __syncthreads();
+                pr.template stamp<4>();
+#pragma unroll
+                for (int u = 0; u < RF; u++) {
+                    const unsigned long long key = ((unsigned long long)r[u].y << 32) | r[u].x;
+                    uint32_t m = msk[u];
+                    if (m) {
+                        const float4 nq = FUSED ? post_normal(nv[u]) : nv[u];
+                        while (m) {
+                            const int bit = __ffs((int)m) - 1;
+                            m &= m - 1;
+                            const int px = p0s[u] + (bit >> 3) * W + (bit & 7);
+                            if (keys[px] == key) store3(nplane + NSTRIDE * (ptrdiff_t)px, nq.x, nq.y, nq.z);
+                        }
+                    }
+                }
+                for (uint32_t j = 64 * RF + lane; j < total_w; j += 64) {
+                    const uint32_t slot = wl[j];
+                    const uint4 rr = Rbase[2 * slot];   // (an L1 / L2 hit: read a moment ago)
+                    const unsigned long long key = ((unsigned long long)rr.y << 32) | rr.x;
+                    const int x0 = (int)(rr.z & 0xFFFFu), y0 = (int)(rr.z >> 16);
+                    const int p0 = (y0 - r0) * W + x0;
+                    uint32_t m = rr.w & window_rows_below(r1 - y0) & ~window_rows_below(r0 - y0);
+                    uint32_t won = 0;
+                    while (m) {
+                        const int bit = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        if (keys[p0 + (bit >> 3) * W + (bit & 7)] == key) won |= 1u << bit;
+                    }
+                    if (won) {
+                        float4 nq = Nbase[2 * slot];
+                        if (FUSED) nq = post_normal(nq);
+                        while (won) {
+                            const int bit = __ffs((int)won) - 1;
+                            won &= won - 1;
+                            store3(nplane + NSTRIDE * (ptrdiff_t)(p0 + (bit >> 3) * W + (bit & 7)), nq.x, nq.y, nq.z);
+                        }
+                    }
+                }
+                pr.template stamp<5>();   // winners' normals stored
+                if (FUSED)
+                    write_strip_fused<BLOCK>(a, b, r0, npix, keys);
+                else
+                    write_strip<BLOCK, true>(a, b, r0, npix, keys, vx, vy, vz);
+                pr.finish(0);
+                return;
+            }
+            __syncthreads();   // (general path: everyone has read the verdicts before wtot is reused)
+        }
+    }
     for (int pass = 0; pass < 2; pass++) {
         for (int c0 = 0; c0 < a.nseg; c0 += BLOCK) {
             const uint4* Rbase = a.recs + ((size_t)b * a.nseg + c0) * (2 * SEG);   // record k at [2k], its normal at [2k + 1]
