@@ -269,7 +269,7 @@ __device__ __forceinline__ void write_strip(const RenderArgs& a, int b, int r0, 
         // lane: neighbouring lanes hold neighbouring pixels -> neighbouring triangles -> shared table lines.
         const float4* __restrict__ tws = a.tritex_ws + (a.tex_stride ? (size_t)b * ntri : 0);
         const unsigned long long KBG = bg_key();
-        constexpr int UNR = 4;
+        constexpr int UNR = 8;   // a 10-row strip of 200 pixels is 7.8 pixels per thread of 256: ONE trip, one gather round trip
         for (int i0 = tid; i0 < npix; i0 += BLOCK * UNR) {
             unsigned long long kk[UNR];
             bool cov[UNR];
