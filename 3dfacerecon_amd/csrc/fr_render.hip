@@ -563,11 +563,11 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
             // the certified HITS so that phase B skips their test measured no further gain.)
             if ((a.use_filter & 2) && surv[u] && single[u]) {
                 const float v0x = x3[u] - x1[u], v0y = y3[u] - y1[u], v1x = x2[u] - x1[u], v1y = y2[u] - y1[u];
-                const float D = v0x * v1y - v0y * v1x;
+                const float D = __builtin_fmaf(v0x, v1y, -(v0y * v1x));   // (fused: one rounding fewer than the bound assumes)
                 const float M0 = fmaxf(fmaxf(fabsf(v0x), fabsf(v0y)), fmaxf(fabsf(v1x), fabsf(v1y)));
                 const float S = M0 * M0;
                 const float v2x = fx0 - x1[u], v2y = fy0 - y1[u];
-                const float A = v2x * v1y - v2y * v1x, Bq = v0x * v2y - v0y * v2x, C = (D - A) - Bq;
+                const float A = __builtin_fmaf(v2x, v1y, -(v2y * v1x)), Bq = __builtin_fmaf(v0x, v2y, -(v0y * v2x)), C = (D - A) - Bq;
                 const bool certain = (M0 < 1073741824.0f) && (M0 > 9.094947017729282e-13f) && (fabsf(D) >= 0.00390625f * S) &&
                                      fminf(fminf(fabsf(A), fabsf(Bq)), fabsf(C)) >= 1.52587890625e-05f * S;
                 const bool in = D > 0.0f ? fminf(fminf(A, Bq), C) > 0.0f : fmaxf(fmaxf(A, Bq), C) < 0.0f;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
                 // v > 1, u + v < 1 -- whose exact margins are >= 2^-17 -- fall the same way.  NaN / Inf / huge / tiny
                 // (fp32 underflow) inputs fail the certificate and take the fp64 path.
                 const float v0x = x3 - x1, v0y = y3 - y1, v1x = x2 - x1, v1y = y2 - y1;
-                const float D = v0x * v1y - v0y * v1x;
+                const float D = __builtin_fmaf(v0x, v1y, -(v0y * v1x));   // (fused: one rounding fewer than the bound assumes)
                 // every tested pixel centre Q lies inside the triangle's bbox, so |Q - P1| <= max_i |P_i - P1| per axis:
                 // the largest component of v0, v1 bounds v2's as well and S is a per-triangle constant
                 const float M0 = fmaxf(fmaxf(fabsf(v0x), fabsf(v0y)), fmaxf(fabsf(v1x), fabsf(v1y)));
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void raster_emit_kernel(RenderArgs a) {
 #pragma clang loop unroll(disable)
                 for (int k = 0; k < npx; k++) {
                     const float v2x = (float)(x_min + dx) - x1, v2y = (float)yy - y1;
-                    const float A = v2x * v1y - v2y * v1x, Bq = v0x * v2y - v0y * v2x, C = (D - A) - Bq;
+                    const float A = __builtin_fmaf(v2x, v1y, -(v2y * v1x)), Bq = __builtin_fmaf(v0x, v2y, -(v0y * v2x)), C = (D - A) - Bq;
                     const bool certain = tri_ok && fminf(fminf(fabsf(A), fabsf(Bq)), fabsf(C)) >= tm;
                     const bool in = dpos ? fminf(fminf(A, Bq), C) > 0.0f : fmaxf(fmaxf(A, Bq), C) < 0.0f;
                     const uint32_t bm = 1u << (bit + dx);
