@@ -6,7 +6,7 @@
 // tools/emit_probe.py, which reduces the stamps to the phase shares of a workgroup's life.
 #include "../3dfacerecon_amd/csrc/fr_render.hip"
 
-namespace fr { int opt(Opt o) { return o == OPT_RESOLVE_OPT ? 1 : o == OPT_EMIT_FILTER ? 3 : 0; } }
+namespace fr { int opt(Opt o) { return o == OPT_RESOLVE_OPT ? 2 : o == OPT_EMIT_FILTER ? 3 : 0; } }   // the product's defaults
 
 __device__ unsigned long long* g_emit_stamps;
 

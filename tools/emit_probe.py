@@ -126,11 +126,12 @@ def main():
         assert all(torch.equal(a, b) for a, b in zip(plan.outputs(), ref)), "stamped resolver changed the planes"
         st = stamps.cpu().numpy().reshape(-1, 4, 10)[:nb].astype(np.float64)
         t = st[:, :, :9]
-        # stamps: 0 entry, 1 offsets back, 2 scans + slot list, 3 record loads issued, 4 records back + LDS max, 5 barrier,
-        # 6 winners' normals stored, 7 unused (= 0 on the fast path), 8 end (plane stores issued)
-        fast = t[:, 0, 4] > 0          # bins that took the single-trip register path
-        names = [("entry -> offsets back (keys initialised meanwhile)", 0, 1), ("two block scans + slot list + barrier", 1, 2),
-                 ("slot list read, record + normal loads issued", 2, 3), ("records back, LDS max", 3, 4), ("barrier", 4, 5),
+        # stamps: 0 entry, 1 offsets back, 2 wave scan + wave list, 3 record loads issued, 4 LDS-only barrier + records back +
+        # LDS max, 5 barrier, 6 winners' normals stored, 7 unused (= 0 on the fast path), 8 end (plane stores issued)
+        fast = t[:, 0, 4] > 0          # bins that took the wave-local register path
+        names = [("entry -> offsets back (keys initialised meanwhile)", 0, 1), ("wave scan (DPP) + the wave's slot list", 1, 2),
+                 ("slot list read, record + normal loads issued", 2, 3),
+                 ("LDS-only barrier, records back, LDS max (+ the busy waves' overflow loop)", 3, 4), ("barrier", 4, 5),
                  ("winners' normals stored", 5, 6), ("plane writer: keys -> texture-mean gathers -> stores issued", 6, 8)]
         rr = {"bins": int(nb), "bins_on_the_single_trip_path": int(fast.sum()), "segments_cycles_median_over_waves": {},
               "wave_life_cycles_median": float(np.median(t[fast][:, :, 8] - t[fast][:, :, 0]))}
