@@ -81,6 +81,20 @@ __device__ __forceinline__ void bwd_rotation(const BwdArgs& a, int b, float* R9)
     for (int i = 0; i < 9; i++) R9[i] = (float)Rm[i];
 }
 
+// Sum over the 64 lanes of a wave in a FIXED order (pairs, quads, half rows, rows, then the row totals passed on with
+// row_bcast:15 / row_bcast:31): six v_add_f32_dpp, result valid in lane 63.  All 64 lanes must be active.
+#define FR_DPP_ADD(x, ctrl, rmask, bc) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, bc))
+__device__ __forceinline__ float wave_sum_to_lane63(float x) {
+    FR_DPP_ADD(x, 0x111, 0xf, true);    // row_shr:1
+    FR_DPP_ADD(x, 0x112, 0xf, true);    // row_shr:2
+    FR_DPP_ADD(x, 0x114, 0xf, true);    // row_shr:4
+    FR_DPP_ADD(x, 0x118, 0xf, true);    // row_shr:8  -> lane 15 of every row holds the row's sum
+    FR_DPP_ADD(x, 0x142, 0xa, false);   // row_bcast:15 into rows 1 and 3
+    FR_DPP_ADD(x, 0x143, 0xc, false);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+    return x;
+}
+#undef FR_DPP_ADD
+
 // ---- prepass: 64 vertices x 64 batch columns per workgroup -------------------------------------------------------------
 __global__ __launch_bounds__(256) void bwd_prepass_kernel(BwdArgs a) {
     __shared__ float Mt[64][13];                 // f*R (9), t (3), 1/f or 0
@@ -148,16 +162,11 @@ __global__ __launch_bounds__(256) void bwd_prepass_kernel(BwdArgs a) {
 #pragma unroll
             for (int c = 0; c < 3; c++)
                 tile[c][lane][bslot] = __builtin_fmaf(m[6 + c], dq2, __builtin_fmaf(m[3 + c], dq1, m[c] * dq0));
-            // fixed-order wave reduction over the 64 vertices
-            float r0 = dq0, r1 = dq1, r2 = dq2, r3 = fs;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                r0 += __shfl_xor(r0, d);
-                r1 += __shfl_xor(r1, d);
-                r2 += __shfl_xor(r2, d);
-                r3 += __shfl_xor(r3, d);
-            }
-            if (lane == 0) {
+            // fixed-order wave reduction over the 64 vertices (six DPP adds per value, the total lands in lane 63; the
+            // __shfl_xor butterfly was 24 dependent ds_bpermute trips per column)
+            const float r0 = wave_sum_to_lane63(dq0), r1 = wave_sum_to_lane63(dq1), r2 = wave_sum_to_lane63(dq2),
+                        r3 = wave_sum_to_lane63(fs);
+            if (lane == 63) {
                 float* pp = a.pose_part + ((size_t)blockIdx.x * 64 + b) * 4;
                 pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3 * m[12];
             }
