@@ -423,3 +423,39 @@ def test_emit_phase_refuses_a_table_packed_for_other_arguments(oracle):
     ws2 = torch.zeros_like(ws)
     run(*b, ws2, 4)
     assert_render_equal(run(*a, ws2, 3), empty, "table of another shape")
+
+
+@pytest.mark.parametrize("nsegs,with_big", [(4, False), (8, False), (12, False), (5, True)])
+def test_resolver_wave_local_front_overflow_and_fallback(oracle, nsegs, with_big):
+    """The resolver's wave-local front (FR_RESOLVE_OPT=2) keeps six records per lane in registers, sends what a busy wave has
+    beyond 384 through a reload loop and hands a bin whose wave holds more than 768 records -- or any big record -- to the
+    general path.  One-pixel triangles, all of them inside strip 0, 504 per segment: with 4 segments every wave owns 504
+    records (overflow loop), with 8 it owns 1,008 (general path), with 12 the first strip holds 6,048 records (longer than
+    the LDS slot list: the search path); a half-screen triangle makes bucket 0 non-empty.  Many triangles share a pixel
+    (depth ties and near-ties), every plane bit for bit; the same scene through the block-wide front (FR_RESOLVE_OPT=1) and
+    the two-pass resolver (0) gives the same bits."""
+    host = pkg("_lib")
+    rs = np.random.RandomState(100 + nsegs)
+    H = W = 64
+    ntri = 504 * nsegs
+    nver = 3 * ntri + 3
+    px = rs.randint(0, W, ntri).astype(np.float32)
+    py = rs.randint(0, 4, ntri).astype(np.float32)          # rows 0..3 = strip 0 at this size
+    ver = np.zeros((1, 3, nver), np.float32)
+    k = np.arange(ntri)
+    jit = rs.uniform(-0.05, 0.05, (6, ntri)).astype(np.float32)
+    ver[0, 0, 3 * k] = px - 0.3 + jit[0]; ver[0, 1, 3 * k] = py - 0.3 + jit[1]
+    ver[0, 0, 3 * k + 1] = px + 0.4 + jit[2]; ver[0, 1, 3 * k + 1] = py - 0.2 + jit[3]
+    ver[0, 0, 3 * k + 2] = px + jit[4]; ver[0, 1, 3 * k + 2] = py + 0.4 + jit[5]
+    ver[0, 2, :3 * ntri] = np.repeat(rs.randint(0, 40, ntri).astype(np.float32) * 0.25, 3)   # few distinct depths: ties
+    tri = np.stack([3 * k, 3 * k + 1, 3 * k + 2]).astype(np.float32)
+    if with_big:   # one triangle over half the screen (inside it: the reference drops a triangle whose bbox leaves the image), behind everything
+        ver[0, :, 3 * ntri:] = np.array([[0.5, 62.5, 0.5], [0.5, 0.5, 62.5], [-5, -5, -5]], np.float32)
+        tri = np.concatenate([tri, np.array([[3 * ntri], [3 * ntri + 1], [3 * ntri + 2]], np.float32)], axis=1)
+    tex = rs.uniform(0, 1, (1, 3, nver)).astype(np.float32)
+    want = oracle.render_depth(ver, tri, tex, H, W)
+    assert (want[3] >= 0).mean() > (0.4 if with_big else 0.05)
+    for opt in (2, 1, 0):
+        with host.options(FR_RESOLVE_OPT=opt):
+            got = render_gpu(ver, tri, tex, H, W)
+        assert_render_equal(got, want, "FR_RESOLVE_OPT=%d, %d segments%s" % (opt, nsegs, ", big triangle" if with_big else ""))
