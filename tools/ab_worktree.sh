@@ -1,3 +1,9 @@
+#!/bin/bash
+# Same-box A/B of the working tree against the COMMITTED library (how the second half of round 3 was measured; resolves
+# +-0.2 us where cross-session comparisons are lost in the +-5 % spread between boxes):
+#   git worktree add -f _old HEAD && (cd _old && python -c "import __graft_entry__ as g; g.build()")   # here, once per HEAD
+#   gpurun -- 'bash tools/ab_worktree.sh 3'                                                              # on the GPU box
+# (_old/ is git-ignored but travels with the gpurun snapshot; remove it with `git worktree remove --force _old`.)
 # same-box A/B: committed library in _old vs the working tree, N rounds
 N=${1:-3}
 for i in $(seq $N); do for v in old new; do
