@@ -39,6 +39,14 @@ def _ops():
     return _load("_fr_hotpath_ops", os.path.join("rendering_layer", "ops.py"))
 
 
+def _publish(device):
+    """A lazily built constant image is packed on whichever stream first needs it (possibly autograd's backward stream) and
+    then cached with no event: wait for the pack kernel ONCE, here, so that a later consumer on any other stream finds the
+    image complete.  (Not under graph capture, where a synchronize is illegal: the capture's own stream order covers it.)"""
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(device).synchronize()
+
+
 class PackedBasis:
     """The constant basis (a tf.constant of the reference model, network.py:41-43) in the layouts the decode kernels
     stream: the f32 MFMA-fragment image, built at once (fr_decode_pack_basis), and -- only if the opt-in Q30 arithmetic
@@ -56,13 +64,18 @@ class PackedBasis:
             rc = L.fr_decode_pack_basis(h.ptr(mu), h.ptr(pc_shape), h.ptr(pc_exp), nvert, ndim_shape, ndim_exp,
                                         h.ptr(self.image), nbytes, h.stream_ptr(device))
         h.check(rc, "fr_decode_pack_basis")
+        _publish(device)
         self._qimage = None
         self._image_t = None   # K-major image for the backward's reduction over the vertices, built at the first backward
+        self._t_owner = None   # another PackedBasis of the SAME pc_shape / pc_exp whose image_t this one shares (the K-major
+                               # image does not contain mu, so a mu = 0 twin needs no second 153 MB copy)
         self.q30_ws_bytes = L.fr_decode_q30_workspace_bytes(ndim_shape, ndim_exp)
 
     def image_t(self):
         """The basis packed for the decode backward (fr_decode_backward_pack_basis), built on first use: callers that never
         take a gradient never hold it."""
+        if self._t_owner is not None:
+            return self._t_owner.image_t()
         if self._image_t is None:
             h = _host()
             L = h.lib()
@@ -72,6 +85,7 @@ class PackedBasis:
                 rc = L.fr_decode_backward_pack_basis(h.ptr(self.pc_shape), h.ptr(self.pc_exp), self.nvert, self.ndim_shape,
                                                      self.ndim_exp, h.ptr(buf), nbytes, h.stream_ptr(self.device))
             h.check(rc, "fr_decode_backward_pack_basis")
+            _publish(self.device)
             self._image_t = buf
         return self._image_t
 
@@ -90,6 +104,7 @@ class PackedBasis:
                 rc = L.fr_decode_q30_pack(h.ptr(self.mu), h.ptr(self.pc_shape), h.ptr(self.pc_exp), self.nvert,
                                           self.ndim_shape, self.ndim_exp, h.ptr(buf), nbytes, h.stream_ptr(self.device))
             h.check(rc, "fr_decode_q30_pack")
+            _publish(self.device)
             self._qimage = buf
         return self._qimage
 
@@ -242,6 +257,7 @@ class FaceRecNet:
         if self._basis_nomu is None:
             self._basis_nomu = PackedBasis(torch.zeros_like(self.mu), self.pc_shape, self.pc_exp, self.nvert,
                                            self.ndim_shape, self.ndim_exp, self.device)
+            self._basis_nomu._t_owner = self._basis   # same pc_shape / pc_exp: one K-major backward image for both
         pose = torch.zeros((B, self.ndim_pose), dtype=torch.float32, device=g.device)
         pose[:, 6] = 1.0
         eye = torch.eye(3, dtype=torch.float32, device=g.device)[None].repeat(B, 1, 1).contiguous()

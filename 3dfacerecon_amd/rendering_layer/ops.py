@@ -106,6 +106,11 @@ def _workspace(dev, nbytes):
 
 def _render_phases(ent, cached, tri_c, geom):
     """7 (pack + emit + resolve) or 3 when the entry's triangle table was packed from this very list for this geometry."""
+    # an inference tensor (created under torch.inference_mode()) has no version counter: in-place writes to it cannot be
+    # seen, so its table is never reused -- packed every call, like a caller that passes a new tensor each time
+    if tri_c.is_inference():
+        ent.tri_ref = ent.tri_key = None
+        return 7
     key = (tri_c._version, tri_c.data_ptr()) + geom
     if cached and ent.tri_ref is not None and ent.tri_ref() is tri_c and ent.tri_key == key:
         return 3

@@ -82,7 +82,12 @@ def _stack(files, batch_size, sample_shape, load):
     assert len(files) == batch_size
     out = np.zeros((batch_size,) + tuple(sample_shape))
     for row, path in zip(out, files):
-        row[...] = np.reshape(load(path), sample_shape)
+        arr = np.asarray(load(path))
+        # same element count is not enough: a 100x400 image must not be folded into a 200x200 plane (the reference's
+        # `input_image[i,:,:,0] = im_gray - mean` raises on that mismatch)
+        if tuple(d for d in arr.shape if d != 1) != tuple(d for d in sample_shape if d != 1):
+            raise ValueError("%s: sample of shape %s does not fit %s" % (path, arr.shape, tuple(sample_shape)))
+        row[...] = np.reshape(arr, sample_shape)
     return out
 
 

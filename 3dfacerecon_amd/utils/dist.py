@@ -78,13 +78,91 @@ def gather_over_ranks(value, device="cpu"):
     return [float(x.item()) for x in out]
 
 
+def device_identity(device="cpu"):
+    """What THIS rank computes on: host, device name and a device id that is unique per physical GPU on the node (the PCI
+    bus id; the uuid when torch exposes it).  A CPU rank (the gloo tests) reports its process id."""
+    import socket
+    ident = {"host": socket.gethostname(), "pid": os.getpid()}
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    if dev.type == "cuda" and torch.cuda.is_available():
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(idx)
+        ident.update(device="cuda:%d" % idx, name=pr.name, cus=getattr(pr, "multi_processor_count", None),
+                     hbm_gib=round(pr.total_memory / 2.0 ** 30, 1))
+        bus = [getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        ident["pci"] = "%04x:%02x:%02x" % tuple(bus) if all(b is not None for b in bus) else None
+        uuid = getattr(pr, "uuid", None)
+        ident["uuid"] = str(uuid) if uuid is not None else None
+        ident["id"] = "%s/%s" % (ident["host"], ident["uuid"] or ident["pci"] or ident["device"])
+    else:
+        ident.update(device="cpu", name="cpu", pci=None, uuid=None, id="%s/cpu-pid%d" % (ident["host"], ident["pid"]))
+    return ident
+
+
+def collective_library():
+    """The version of the collective library torch would use for backend "nccl" (= RCCL on ROCm), or None."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:  # noqa: BLE001 -- a CPU-only torch build has no nccl module to ask
+        return None
+
+
 def describe(device="cpu"):
     """What the process group itself reports -- so that a bench line can prove what RCCL saw: backend, the world size as
-    dist.get_world_size() returns it, and how many ranks answered a SUM all-reduce of ones."""
+    dist.get_world_size() returns it, how many ranks answered a SUM all-reduce of ones, and WHICH device every rank ran
+    on (`devices`, in rank order; `distinct_devices` = no two ranks share one).  Under backend "nccl" two ranks on one GPU
+    is a broken launch: it raises."""
+    me = device_identity(device)
     if not (dist.is_available() and dist.is_initialized()):
-        return {"backend": None, "world_size": 1, "ranks_reporting": 1}
-    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-            "ranks_reporting": int(round(sum_over_ranks(1.0, device)))}
+        return {"backend": None, "world_size": 1, "ranks_reporting": 1, "devices": [me], "distinct_devices": True,
+                "rccl_version": collective_library()}
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, me)
+    ids = [d["id"] for d in everyone]
+    distinct = len(set(ids)) == len(ids)
+    backend = dist.get_backend()
+    if backend == "nccl" and not distinct:
+        raise RuntimeError("ranks share a GPU under RCCL: %s" % ids)
+    return {"backend": backend, "world_size": dist.get_world_size(),
+            "ranks_reporting": int(round(sum_over_ranks(1.0, device))), "devices": everyone,
+            "distinct_devices": distinct, "rccl_version": collective_library() if backend == "nccl" else None}
+
+
+def allreduce_preflight(megabytes, device="cpu", iters=5):
+    """Times a SUM all-reduce of `megabytes` MB of fp32 (config 4's ResNet-101 + FC gradient is ~302 MB: SURVEY.md 5)
+    on the default group: -> {bytes, ms (median of `iters`, MAX over ranks), algbw_GBs = bytes / t,
+    busbw_GBs = algbw * 2 (n - 1) / n: the per-link figure a ring all-reduce is bound by}.  None without a group."""
+    import time
+    if not (dist.is_available() and dist.is_initialized()) or megabytes <= 0:
+        return None
+    n = dist.get_world_size()
+    cdev = _collective_device(device)
+    t = torch.ones((int(megabytes * 1e6) // 4,), dtype=torch.float32, device=cdev)
+    on_gpu = torch.device(cdev).type == "cuda"
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize(cdev)
+
+    dist.all_reduce(t)   # warm-up: communicator set-up, buffer registration
+    sync()
+    times = []
+    for _ in range(iters):
+        t.fill_(1.0)
+        dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        dist.all_reduce(t)
+        sync()
+        times.append(max_over_ranks(time.perf_counter() - t0, device))
+    ok = bool((t == float(n)).all().item())
+    times.sort()
+    sec = times[len(times) // 2]
+    nbytes = t.numel() * 4
+    return {"bytes": nbytes, "ms": 1e3 * sec, "algbw_GBs": nbytes / sec / 1e9,
+            "busbw_GBs": nbytes / sec / 1e9 * 2.0 * (n - 1) / n, "sum_correct": ok, "iters": iters,
+            "what": "one SUM all-reduce of config 4's gradient size on the bench's own process group"}
 
 
 def bench_partition(batch, rank, world, scaling="weak"):

@@ -42,7 +42,8 @@ const char* fr_strerror(int code);
  * getenv -- and can be changed afterwards only through fr_set_option:
  *   FR_DECODE_IMPL (0 | 1 = "loop": generic decode kernel)   FR_DECODE_WIDE (1 | 0)   FR_DECODE_NBW (0 = auto | 1 | 4)
  *   FR_DECODE_WAVES (16 | 8)   FR_DECODE_NT (1 | 0: default cache policy for the basis stream)
- *   FR_RESOLVE_OPT (1 | 0)   FR_EMIT_FILTER (bits 0-1, default 3)   FR_RENDER_IMPL (0 | 1 = "scan": strip-scan fallback)
+ *   FR_RESOLVE_OPT (2 = default: wave-local front for 256-thread bins | 1 = block-wide list, single-trip bins keep their
+ *   records in registers | 0 = two-pass resolver)   FR_EMIT_FILTER (bits 0-1, default 3)   FR_RENDER_IMPL (0 | 1 = "scan": strip-scan fallback)
  *   FR_RESOLVE_BLOCK (0 = auto | 256 | 512 | 1024)   FR_RENDER_ROWS (0 = auto | rows per screen strip)
  * None of them changes a result bit (tests/test_render_gpu.py, tests/test_decode_gpu.py hold every setting to the oracle).
  * Returns FR_OK or FR_ERR_INVALID_ARG (unknown name). */

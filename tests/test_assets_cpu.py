@@ -99,6 +99,10 @@ def test_generators_roundtrip(tmp_path, synth):
         dp.prepare_input_image([os.path.join(root, "face_images", "nope.jpg")], 1, [12, 10])
     with pytest.raises(IOError):
         dp.prepare_input_label([os.path.join(root, "labels", "Ana/0001.txt")], 1, 100)
+    # an image with the right pixel COUNT but the wrong height x width must raise, not be folded into the plane (the
+    # reference's `input_image[i,:,:,0] = ...` assignment raises a ValueError there)
+    with pytest.raises(ValueError):
+        dp.prepare_input_image([os.path.join(root, "face_images", "Ana/0001.jpg")], 1, [6, 20])
     g3 = dp.trainval_generator(3, [12, 10], 235, dataset=root, phase="train")
     next(g3)
     with pytest.raises(AssertionError):

@@ -39,9 +39,10 @@ def _worker(rank, world, port, q):
     first, nloc, nglob = d.bench_partition(64, rank, world, "strong")
     wfirst, wloc, wglob = d.bench_partition(64, rank, world, "weak")
     info = d.describe()
+    pre = d.allreduce_preflight(0.5, iters=2)
     times = d.gather_over_ranks(0.1 * (rank + 1))
     owned = d.sum_over_ranks(nloc)
-    q.put((rank, lo, hi, t, faces, float(P.sum()), (first, nloc, nglob, wfirst, wloc, wglob, info, times, owned)))
+    q.put((rank, lo, hi, t, faces, float(P.sum()), (first, nloc, nglob, wfirst, wloc, wglob, info, times, owned, pre)))
     d.finalize()
 
 
@@ -59,7 +60,15 @@ def test_two_rank_gloo():
     (r0, lo0, hi0, t0, f0, s0, x0), (r1, lo1, hi1, t1, f1, s1, x1) = res
     # strong scaling: rank 0 owns faces [0, 32), rank 1 [32, 64) of the one 64-face batch; weak: 64 each, 128 in all
     assert x0[:6] == (0, 32, 64, 0, 64, 128) and x1[:6] == (32, 32, 64, 64, 64, 128)
-    assert x0[6] == x1[6] == {"backend": "gloo", "world_size": 2, "ranks_reporting": 2}
+    for info in (x0[6], x1[6]):
+        assert (info["backend"], info["world_size"], info["ranks_reporting"]) == ("gloo", 2, 2)
+        # the line proves WHICH device every rank ran on: one identity per rank, in rank order, all different
+        assert len(info["devices"]) == 2 and info["distinct_devices"] and info["rccl_version"] is None
+        assert len({dv["id"] for dv in info["devices"]}) == 2 and all(dv["device"] == "cpu" for dv in info["devices"])
+    assert x0[6]["devices"] == x1[6]["devices"]            # every rank holds the same, complete table
+    for pre in (x0[9], x1[9]):                             # the all-reduce preflight: right sum, a bandwidth, the same on both
+        assert pre["sum_correct"] and pre["bytes"] == 500000 and pre["ms"] > 0 and pre["busbw_GBs"] == pre["algbw_GBs"]
+    assert x0[9]["ms"] == x1[9]["ms"]
     assert x0[7] == x1[7] == [0.1, 0.2] and x0[8] == x1[8] == 64
     assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)          # disjoint, covering, no overlap
     assert t0 == t1 == 0.5                                 # MAX over ranks
@@ -72,6 +81,8 @@ def test_single_process_helpers_are_noops():
     d = importlib.import_module("3dfacerecon_amd.utils.dist")
     assert d.max_over_ranks(1.5) == 1.5 and d.sum_over_ranks(3) == 3.0
     assert d.gather_over_ranks(2.5) == [2.5] and d.describe()["world_size"] == 1
+    assert d.describe()["distinct_devices"] and d.describe()["devices"][0]["device"] == "cpu"
+    assert d.allreduce_preflight(1.0) is None
     assert d.bench_partition(64, 0, 1, "strong") == (0, 64, 64) and d.bench_partition(64, 3, 8, "strong") == (24, 8, 64)
     assert d.bench_partition(10, 7, 8, "strong") == (9, 1, 10) and d.bench_partition(3, 7, 8, "strong")[1] == 0
     d.barrier()
