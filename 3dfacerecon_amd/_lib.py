@@ -151,6 +151,11 @@ def _bind(L):
     L.fr_decode_render_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _vp,
                                            ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, _i]
     L.fr_decode_render_forward.restype = _i
+    L.fr_decode_render_pipelined_supported.argtypes = [_i] * 5
+    L.fr_decode_render_pipelined_supported.restype = _i
+    L.fr_decode_render_pipelined.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _vp, _vp,
+                                             ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, _i]
+    L.fr_decode_render_pipelined.restype = _i
     L.fr_set_option.argtypes = [ctypes.c_char_p, _i]
     L.fr_set_option.restype = _i
     L.fr_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
@@ -181,6 +186,7 @@ EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_r
            "fr_render_depth_backward_workspace_bytes", "fr_render_depth_backward_ws", "fr_set_option", "fr_get_option",
            "fr_decode_q30_image_bytes", "fr_decode_q30_pack", "fr_decode_q30_workspace_bytes", "fr_decode_3dmm_q30",
            "fr_decode_render_vertex_pitch", "fr_decode_render_vertex_bytes", "fr_decode_render_forward",
+           "fr_decode_render_pipelined_supported", "fr_decode_render_pipelined",
            "fr_decode_backward_basis_bytes", "fr_decode_backward_pack_basis", "fr_decode_3dmm_backward_packed"]
 
 

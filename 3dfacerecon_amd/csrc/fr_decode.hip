@@ -85,11 +85,16 @@ __device__ __forceinline__ float bsel(const typename BFrag<NBW>::type& b, int i)
     if constexpr (NBW == 1) return b;
     else return b[i];
 }
-template <int NBW>
+// TR = false: D[vertex][batch] (a lane holds 4 consecutive vertices of one batch column).  TR = true: the two operands are
+// swapped, D'[batch][vertex] = D^T with the same registers -- lane l then holds vertex l & 15 of batches 4 (l >> 4) + r --
+// bit for bit the same sums (same k order, the products commute).
+template <int NBW, bool TR = false>
 __device__ __forceinline__ void mfma_step(float a, const typename BFrag<NBW>::type& bq, f32x4 (&acc)[NBW]) {
 #pragma unroll
-    for (int nb = 0; nb < NBW; nb++)
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bsel<NBW>(bq, nb), acc[nb], 0, 0, 0);
+    for (int nb = 0; nb < NBW; nb++) {
+        if constexpr (TR) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bsel<NBW>(bq, nb), a, acc[nb], 0, 0, 0);
+        else acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bsel<NBW>(bq, nb), acc[nb], 0, 0, 0);
+    }
 }
 // LDS image of the parameters (B operand): element (k, column j of 16, block nb) sits at k*16*NBW + pcol(k, j)*NBW + nb.
 // For NBW <= 2 the column is XOR-swizzled with the k index: the prologue stores the image with 16 consecutive k per
@@ -325,8 +330,11 @@ __device__ __forceinline__ void ring_wait(f32x4& slot) {
 // PRIO: static issue priorities for the four waves that share a SIMD (waves w, w+4, w+8, w+12 get 0..3): with equal
 // priorities the sixteen waves of a CU advance in lock-step and reach their epilogues together; ranked, a SIMD tends to run
 // them one after the other, which spreads the epilogues and their stores (decode -1 us dense, -2 us with aligned rows).
+// TR: transposed accumulators (mfma_step) -- the epilogue then stores one dword per lane, and the sixteen lanes of a quarter
+// wave write one batch row's 64 contiguous bytes (decode_store_tr), where the default form's store instruction scatters 16
+// bytes per lane over sixteen rows.
 template <int GS, int GE, int R, int NBW, int DEC_WAVES, int MB = 64, int WPE = DEC_WAVES / 4, bool NT = false, class PR = NoProbe,
-          bool PRIO = false>
+          bool PRIO = false, bool TR = false>
 __global__ __launch_bounds__(DEC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void decode_ring_kernel(DecodeArgs a) {
     PR pr;
@@ -357,7 +365,8 @@ void decode_ring_kernel(DecodeArgs a) {
     int sw[4];
     lane_swizzle<NBW>(lane, sw);
     const unsigned voffA = (unsigned)lane * 16u;         // this lane's 16 bytes of a 1 KiB A fragment
-    const unsigned voffM = (unsigned)(lane >> 4) * 16u;  // this lane's 4 vertices of a 64-byte mu row
+    // this lane's 4 vertices of a 64-byte mu row (TR: the aligned quad that holds ITS vertex, lane & 15)
+    const unsigned voffM = TR ? (unsigned)(lane & 12) * 4u : (unsigned)(lane >> 4) * 16u;
     const char* Ab = reinterpret_cast<const char*>(a.A);
     const char* Mb = reinterpret_cast<const char*>(a.mu_p);
     constexpr size_t tile_bytes = (size_t)G * 3 * 1024;
@@ -447,13 +456,18 @@ void decode_ring_kernel(DecodeArgs a) {
                     // skipped: their products are +0 (zero basis x zero parameter) and the chains, started from +0, are
                     // never -0, so adding them changes nothing -- and the oracle's chains do not contain them
                     const int live = (g == GS - 1) ? ks_s : (g == G - 1) ? ks_e : 4;
-                    mfma_step<NBW>(af.x, bq[0], c[cc]);
-                    if (live > 1) mfma_step<NBW>(af.y, bq[1], c[cc]);
-                    if (live > 2) mfma_step<NBW>(af.z, bq[2], c[cc]);
-                    if (live > 3) mfma_step<NBW>(af.w, bq[3], c[cc]);
+                    mfma_step<NBW, TR>(af.x, bq[0], c[cc]);
+                    if (live > 1) mfma_step<NBW, TR>(af.y, bq[1], c[cc]);
+                    if (live > 2) mfma_step<NBW, TR>(af.z, bq[2], c[cc]);
+                    if (live > 3) mfma_step<NBW, TR>(af.w, bq[3], c[cc]);
                 }
             } else {  // mu fragment of coordinate cc: v = (mu + S) + E   (network.py:159)
-                const f32x4 m = ring[f % R];
+                f32x4 m = ring[f % R];
+                if constexpr (TR) {   // one vertex per lane: its mu, for all four batches in the registers
+                    const int sel = lane & 3;
+                    const float mv = sel == 0 ? m.x : sel == 1 ? m.y : sel == 2 ? m.z : m.w;
+                    m = (f32x4){mv, mv, mv, mv};
+                }
 #pragma unroll
                 for (int nb = 0; nb < NBW; nb++) c[cc][nb] = (m + sv[cc][nb]) + c[cc][nb];
             }
@@ -464,8 +478,10 @@ void decode_ring_kernel(DecodeArgs a) {
             }
         }
         pr.item_mfma_done();
-        if ((PR::bits & 32) == 0 || c[0][0][0] + c[1][0][1] + c[2][NBW - 1][2] == 12345.678f)
-            decode_store<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
+        if ((PR::bits & 32) == 0 || c[0][0][0] + c[1][0][1] + c[2][NBW - 1][2] == 12345.678f) {
+            if constexpr (TR) decode_store_tr<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
+            else decode_store<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
+        }
         pr.item_end();
 #pragma unroll
         for (int cc = 0; cc < 3; cc++)
@@ -525,15 +541,16 @@ static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int cus, size_
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
-template <int GS, int GE, int R, int NBW, int WAVES, int MB = 64, int WPE = WAVES / 4, bool NT = false, bool PRIO = false>
+template <int GS, int GE, int R, int NBW, int WAVES, int MB = 64, int WPE = WAVES / 4, bool NT = false, bool PRIO = false,
+          bool TR = false>
 static int launch_decode_ring(const fr::DecodeArgs& a, size_t lds, int cus, size_t tiles, hipStream_t stream) {
     static unsigned char lds_ok[64];
-    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT, fr::NoProbe, PRIO>),
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT, fr::NoProbe, PRIO, TR>),
                           lds_ok) != hipSuccess)
         return FR_ERR_LAUNCH;
     const int slots = WAVES / a.halves;
     const int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
-    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT, fr::NoProbe, PRIO>), dim3(grid), dim3(WAVES * 64),
+    hipLaunchKernelGGL((fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT, fr::NoProbe, PRIO, TR>), dim3(grid), dim3(WAVES * 64),
                        lds, stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
@@ -585,6 +602,8 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
         else if (ring && waves_env == 8) rc = launch_decode_ring<13, 2, 8, 2, 8, 64, 4>(a, lds, cus, tiles, stream);
         else if (ring && nt_off)
             rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);  // A/B knob: default-policy basis loads
+        else if (ring && opt(OPT_DECODE_STORE) == 1)
+            rc = launch_decode_ring<13, 2, 8, 2, 16, 64, 4, true, true, true>(a, lds, cus, tiles, stream);  // A/B knob: transposed accumulators
         else if (ring)
             // the basis stream carries the non-temporal hint: it is read once per launch, and keeping its 153 MB out of
             // the way leaves the L2 / Infinity Cache to the vertices and hit records the render kernels re-read (measured

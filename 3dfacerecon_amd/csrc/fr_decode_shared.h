@@ -155,4 +155,33 @@ __device__ __forceinline__ void decode_store(const DecodeArgs& a, const f32x4 (&
     }
 }
 
+// The same epilogue for TRANSPOSED accumulators (mfma_step<NBW, true>): register r of lane l is (vertex l & 15, batch
+// 16 * block + 4 * (l >> 4) + r).  One dword per lane per store: the sixteen lanes of a quarter wave write one row's 64
+// contiguous bytes.
+template <int NBW>
+__device__ __forceinline__ void decode_store_tr(const DecodeArgs& a, const f32x4 (&s0)[NBW], const f32x4 (&s1)[NBW],
+                                                const f32x4 (&s2)[NBW], const float* Mt, int tile, int hf, int lane,
+                                                int nbatch, int N) {
+    const int p = tile * TILE_V + (lane & 15);
+    if (p >= N) return;
+    const int q = lane >> 4;
+#pragma unroll
+    for (int nb = 0; nb < NBW; nb++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int bb = 16 * (hf * NBW + nb) + 4 * q + r;
+            if (bb >= nbatch) continue;
+            const float* m = Mt + bb * 12;
+            const float vx = s0[nb][r], vy = s1[nb][r], vz = s2[nb][r];
+            const float qx = __builtin_fmaf(m[2], vz, __builtin_fmaf(m[1], vy, m[0] * vx)) + m[9];
+            const float qy = __builtin_fmaf(m[5], vz, __builtin_fmaf(m[4], vy, m[3] * vx)) + m[10];
+            const float qz = __builtin_fmaf(m[8], vz, __builtin_fmaf(m[7], vy, m[6] * vx)) + m[11];
+            float* ox = a.out + ((size_t)(a.b0 + bb) * 3) * a.pitch + p;
+            ox[0] = qx;
+            ox[a.pitch] = (a.im_size - qy) - 1.0f;  // network.py:168
+            ox[2 * (size_t)a.pitch] = qz;
+        }
+    }
+}
+
 }  // namespace fr

@@ -155,7 +155,16 @@ def parity_gate(plan, net, assets, params_np, H, W, n_faces):
     import torch
     from oracle import oracle as O
     n = min(int(n_faces), plan.B)
-    plan.step()
+    piped = hasattr(plan, "submit")
+    if piped:
+        # the timed route: the planes checked are the ones the FUSED launch's resolve role wrote (batch 1 of two identical
+        # submits), the vertices the ones the second submit decoded (the same parameters: the same values)
+        plan.flush()
+        plan.submit()
+        plan.submit()
+        torch.cuda.synchronize(plan.device)
+    else:
+        plan.step()
     torch.cuda.synchronize(plan.device)
     V = plan.vertex_proj[:n].contiguous().cpu().numpy()   # (the plan hands the vertices over in pitched rows: a strided view)
     got = [t[:n].cpu().numpy() for t in plan.outputs()]
@@ -180,7 +189,11 @@ def parity_gate(plan, net, assets, params_np, H, W, n_faces):
     frac_equal = float((ulp == 0).mean())
     max_ulp = int(ulp.max())
     ok = bad_planes == 0 and bad_decode == 0 and max_ulp <= 2 and frac_equal >= 0.99
-    return {"faces": n, "route": "DecodeRenderPlan (fr_decode_render_forward, phases 8|1|2 on a triangle table packed once)",
+    if piped:
+        plan.flush()
+    return {"faces": n, "route": ("PipelinedPlan (fr_decode_render_pipelined: decode, then ONE launch = emit of this batch || resolve of "
+                                  "the previous one; the planes checked come out of that launch's resolve role)") if piped else
+                                 "DecodeRenderPlan (fr_decode_render_forward, phases 8|1|2 on a triangle table packed once)",
             "mismatching_planes": bad_planes, "planes_checked": 4 * n,
             "decode_host_rotation_mismatching_faces": bad_decode,
             "decode_inkernel_rotation": {"max_ulp": max_ulp, "frac_bit_equal": frac_equal, "bar": "<= 2 ulp, >= 0.99 equal"},
@@ -237,12 +250,27 @@ def main():
                     help="faces per rank the oracle checks before the line is printed (-1 = all of them; 0 = skip, the "
                          "line then carries parity = null and must not be quoted)")
     ap.add_argument("--no-ops-surface", action="store_true", help="skip the operator-surface leg")
+    ap.add_argument("--route", choices=("auto", "pipelined", "serial"), default="auto",
+                    help="pipelined: PipelinedPlan (two batches in flight: decode, then emit(k) || resolve(k-1) in one "
+                         "launch; every timed block runs K submits + the drain, i.e. K batches from parameters to planes); "
+                         "serial: DecodeRenderPlan (three launches per batch).  auto = serial (measured faster, DESIGN.md 4.6)")
+    ap.add_argument("--no-serial-leg", action="store_true", help="skip the serial plan's comparison leg (pipelined route)")
+    ap.add_argument("--allreduce-mb", type=float, default=-1.0,
+                    help="N > 1: time one SUM all-reduce of this many MB on the bench's process group before the timed "
+                         "region (config 4's gradient is ~302 MB) and report bus GB/s.  -1 = 302 under nccl, 4 under gloo; 0 = skip")
+    ap.add_argument("--config", type=int, default=0, choices=(0, 3, 4, 5),
+                    help="3 / 4 / 5: run the caller config of BASELINE.json (examples/coarse_loop.py --config N --steps K) "
+                         "instead of the headline hot-path bench, and print ITS line")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend for N > 1.  nccl (= RCCL) is the product setting.  gloo exists to walk the "
                          "N > 1 control flow on a box with fewer GPUs than ranks (ranks then share devices, LOCAL_RANK "
                          "modulo the device count); the line's dist.backend says gloo, so it cannot pass for an RCCL run")
     args = ap.parse_args()
 
+    if args.config:   # BASELINE.json configs[2..4]: the caller loops, as a child process (nothing here has touched the GPU)
+        cmd = [sys.executable, os.path.join(ROOT, "examples", "coarse_loop.py"), "--config", str(args.config),
+               "--steps", str(args.steps if "--steps" in sys.argv else 5)]
+        sys.exit(subprocess.call(cmd))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world_env == 1 and "RANK" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
@@ -271,63 +299,111 @@ def main():
         params_np = synth.sample_params_batch(args.batch, im_size=H, beta=0.7, seed=3456)[first:first + B]
     else:
         params_np = synth.sample_params_batch(B, im_size=H, beta=0.7, seed=3456 + rank)
-    plan = pipe.DecodeRenderPlan(net, B, H, W)
-    plan.params.copy_(torch.as_tensor(params_np, device=dev))
+    L = pkg("_lib").lib()
+    piped_ok = bool(L.fr_decode_render_pipelined_supported(B, net.nvert, int(net.tri.shape[1]), H, W)) and not net._basis.use_q30()
+    if args.route == "pipelined" and not piped_ok:
+        raise SystemExit("bench.py --route pipelined: fr_decode_render_pipelined does not serve this shape / arithmetic")
+    # auto = the faster route on this hardware: the serial plan (the fused emit || resolve launch measured 112-120 us per step
+    # against 111 us: the two roles bind on the same per-CU vector-memory path and do not overlap)
+    piped = piped_ok and args.route == "pipelined"
+    serial_plan = pipe.DecodeRenderPlan(net, B, H, W)
+    serial_plan.params.copy_(torch.as_tensor(params_np, device=dev))
+    plan = serial_plan
+    if piped:
+        plan = pipe.PipelinedPlan(net, B, H, W)
+        plan.params.copy_(torch.as_tensor(params_np, device=dev))
     torch.cuda.synchronize(dev)
 
     K, Wm = args.steps, args.warmup
     R = args.repeats if args.repeats > 0 else max(10, 600 // max(1, K))
-    for _ in range(Wm):
-        plan.step()
+    # N > 1: one all-reduce of config 4's gradient size on the bench's own process group, before anything is timed
+    ar_mb = args.allreduce_mb
+    if ar_mb < 0:
+        ar_mb = 0.0 if world == 1 else (302.0 if args.dist_backend == "nccl" else 4.0)
+    allreduce = dist_u.allreduce_preflight(ar_mb, device=dev) if world > 1 and ar_mb > 0 else None
+
     # The timed region -- EXACTLY K steps between barrier + synchronize brackets -- is run R times back to back and the
-    # MEDIAN block is reported (min / max alongside): at ~0.13 ms per step a single K = 20 block is 2.6 ms of wall clock,
+    # MEDIAN block is reported (min / max alongside): at ~0.11 ms per step a single K = 20 block is 2.2 ms of wall clock,
     # short enough for clock ramps and host jitter to move it by several per cent.
+    # Pipelined route: a block is K submits + the drain -- K batches go from parameters to planes INSIDE the brackets (the
+    # first step's launch has no previous batch to resolve, the drain resolves the last one: fill and drain are paid in
+    # every block, nothing is carried in from the warm-up or left for later).
     # Per-kernel durations are taken live, inside the timed regions, with HIP events on the launch stream -- on every
-    # EV_EVERY-th step only: an event pair costs a few microseconds of stream bubble, which at ~130 us per step would
+    # EV_EVERY-th step only: an event pair costs a few microseconds of stream bubble, which at ~110 us per step would
     # otherwise tax every step by ~7 %.
     EV_EVERY, EV_FIRST = 10, 5   # steps 5, 15, 25, ...: never the block's first step (it starts on an idle chip)
-    # (events for every block are created up front and the per-block max over ranks is taken after the last block, so
-    # that the host does nothing but barrier + synchronize + clock reads between two timed regions)
-    evs = [{k: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for k in range(min(EV_FIRST, K - 1), K, EV_EVERY)} for _ in range(R)]
-    local, ev_all = [], []
-    for r in range(R):
-        ev = evs[r]
-        dist_u.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for k in range(K):
-            e = ev.get(k)
-            if e is None:
-                plan.step()   # fr_decode_render_forward: one C call, three launches
-            else:  # same three kernels, each bracketed by events (the render op launched phase by phase)
-                e[0].record()
-                plan.decode()
-                e[1].record()
-                plan.render_phase(1)
-                e[2].record()
-                plan.render_phase(2)
-                e[3].record()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        dist_u.barrier()
-        local.append(t1 - t0)
-        ev_all.extend(ev.values())
-    blocks = [dist_u.max_over_ranks(t, device=dev) for t in local]
-    order = sorted(range(R), key=lambda i: blocks[i])
-    elapsed = blocks[order[(R - 1) // 2]]          # the median block (lower median for an even R)
-    per_rank_ms = [1e3 * t / K for t in dist_u.gather_over_ranks(local[order[(R - 1) // 2]], device=dev)]
+
+    def timed_blocks(pl, is_piped, with_events):
+        for _ in range(Wm):
+            pl.submit() if is_piped else pl.step()
+        if is_piped:
+            pl.flush()
+        # (events for every block are created up front and the per-block max over ranks is taken after the last block, so
+        # that the host does nothing but barrier + synchronize + clock reads between two timed regions)
+        evs = [({k: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for k in range(min(EV_FIRST, K - 1), K, EV_EVERY)}
+                if with_events else {}) for _ in range(R)]
+        loc, ev_all = [], []
+        for r in range(R):
+            ev = evs[r]
+            dist_u.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for k in range(K):
+                e = ev.get(k)
+                if e is None:
+                    pl.submit() if is_piped else pl.step()
+                elif is_piped:   # the same two launches, each bracketed by events
+                    e[0].record()
+                    pl.submit_phases(8)
+                    e[1].record()
+                    pl.submit_phases(3)
+                    e[2].record()
+                else:            # the same three kernels, each bracketed by events (the render op launched phase by phase)
+                    e[0].record()
+                    pl.decode()
+                    e[1].record()
+                    pl.render_phase(1)
+                    e[2].record()
+                    pl.render_phase(2)
+                    e[3].record()
+            if is_piped:
+                pl.flush()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            dist_u.barrier()
+            loc.append(t1 - t0)
+            ev_all.extend(ev.values())
+        blk = [dist_u.max_over_ranks(t, device=dev) for t in loc]
+        order = sorted(range(R), key=lambda q: blk[q])
+        med = order[(R - 1) // 2]              # the median block (lower median for an even R)
+        return blk, blk[med], loc[med], ev_all
+
+    blocks, elapsed, local_med, ev_all = timed_blocks(plan, piped, True)
+    per_rank_ms = [1e3 * t / K for t in dist_u.gather_over_ranks(local_med, device=dev)]
     dist_info = dist_u.describe(device=dev)
     faces_per_step = int(round(dist_u.sum_over_ranks(B, device=dev)))   # what the ranks actually ran, counted by the group
+
+    # the serial plan (three launches per batch, nothing in flight across batches) in the same process, same K / W / R
+    serial_elapsed = None
+    if piped and not args.no_serial_leg:
+        _, serial_elapsed, _, _ = timed_blocks(serial_plan, False, False)
 
     # the operator-surface route (allocations + pack_tri every call): same K / W / R, reported beside `value`
     ops_elapsed = ops_same = None
     if not args.no_ops_surface:
-        ops_elapsed, ops_same = ops_surface_leg(net, pkg("rendering_layer.ops"), plan, B, H, W, K, Wm, R, dist_u, dev)
+        serial_plan.step()
+        ops_elapsed, ops_same = ops_surface_leg(net, pkg("rendering_layer.ops"), serial_plan, B, H, W, K, Wm, R, dist_u, dev)
 
     # parity gate: the oracle on every face of the timed route's buffers, on every rank
     parity = None
     if args.parity_faces != 0:
         parity = parity_gate(plan, net, assets, params_np, H, W, B if args.parity_faces < 0 else args.parity_faces)
+        if piped:   # and the two routes against each other: every plane of every face, bit for bit
+            serial_plan.step()
+            plan.step()
+            torch.cuda.synchronize(dev)
+            parity["planes_identical_to_serial_plan"] = bool(all(torch.equal(a, b) for a, b in zip(plan.outputs(), serial_plan.outputs())))
+            parity["ok"] = bool(parity["ok"] and parity["planes_identical_to_serial_plan"])
         all_ok = dist_u.sum_over_ranks(0.0 if parity["ok"] else 1.0, device=dev) == 0.0
         parity["faces_all_ranks"] = int(round(dist_u.sum_over_ranks(parity["faces"], device=dev)))
         parity["mismatching_planes_all_ranks"] = int(round(dist_u.sum_over_ranks(parity["mismatching_planes"], device=dev)))
@@ -338,19 +414,24 @@ def main():
             dist_u.finalize()
             sys.exit(3)
     decode_ms = sum(e[0].elapsed_time(e[1]) for e in ev_all) / len(ev_all)
-    emit_ms = sum(e[1].elapsed_time(e[2]) for e in ev_all) / len(ev_all)
-    resolve_ms = sum(e[2].elapsed_time(e[3]) for e in ev_all) / len(ev_all)
+    if piped:
+        fused_ms = sum(e[1].elapsed_time(e[2]) for e in ev_all) / len(ev_all)
+        emit_ms = resolve_ms = None
+    else:
+        emit_ms = sum(e[1].elapsed_time(e[2]) for e in ev_all) / len(ev_all)
+        resolve_ms = sum(e[2].elapsed_time(e[3]) for e in ev_all) / len(ev_all)
+        fused_ms = None
     cov = float((plan.tri_ind >= 0).float().mean().item())
 
     graph_fps = None
-    if args.graph:
-        plan.capture()
+    if args.graph:   # (the serial plan: three kernel nodes per replay)
+        serial_plan.capture()
         for _ in range(Wm):
-            plan.replay()
+            serial_plan.replay()
         torch.cuda.synchronize(dev)
         g0 = time.perf_counter()
         for _ in range(K):
-            plan.replay()
+            serial_plan.replay()
         torch.cuda.synchronize(dev)
         graph_fps = B * K / (time.perf_counter() - g0)
 
@@ -365,49 +446,78 @@ def main():
         emit_bytes = (4.0 * 3 * N + (4.0 * 3 * T + 4.0 * 3 * N) / B) * B
         resolve_bytes = 4.0 * H * W * 8 * B
         q30 = plan.q30   # FR_DECODE_ARITH=q30 (opt-in, frozen experiment; the default is the f32 chain)
+        ev_note = ("HIP events on the launch stream around each launch of every %dth step of the timed blocks (the step then goes "
+                   "out launch by launch: separate C calls + event bubbles): an UPPER bound of the kernel's duration in the "
+                   "un-bracketed steps; the rocprofv3 average of the same kernel is `rocprofv3_avg_ms` "
+                   "(profiles/round4_kernel_stats.csv, a PROFILED run: slower clock)" % EV_EVERY)
         if q30:   # int8-MFMA blend: the matrix pipe is no longer the bound, the 153 MB basis + 41 MB output stream is
             roof_decode = {"bound": "hbm", "kernel": "q_stage_kernel + decode_q_ring_kernel<16,4,8> (fr_decode_3dmm, Q30)",
                            "achieved": ab["decode"] * B / (decode_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "traffic": None, "avg_ms": decode_ms, "algorithmic_bytes_per_launch": ab["decode"] * B}
         else:
-            roof_decode = {"bound": "mfma", "kernel": "decode_ring_kernel<13,2,8,2,16,64,4,nt,prio> (fr_decode_render_forward, phase 8)",
+            roof_decode = {"bound": "mfma", "kernel": "decode_ring_kernel<13,2,8,2,16,64,4,nt,prio> (phase 8)",
                            "achieved": flops / (decode_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "traffic": None, "avg_ms": decode_ms, "algorithmic_flop_per_launch": flops,
-                           "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9}
-        roof_emit = {"bound": "hbm", "kernel": "raster_emit_kernel (fr_decode_render_forward, phase 1)",
-                     "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "traffic": None, "avg_ms": emit_ms, "algorithmic_bytes_per_launch": emit_bytes}
-        roof_resolve = {"bound": "hbm", "kernel": "resolve_write_kernel<256> (fr_decode_render_forward, phase 2)",
-                        "achieved": resolve_bytes / (resolve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "traffic": None, "avg_ms": resolve_ms, "algorithmic_bytes_per_launch": resolve_bytes}
-        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json:
-        # FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 correction applied as the microarch guide says)
+                           "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9,
+                           "hbm_frac_of_8TBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "algorithmic_bytes_per_launch": ab["decode"] * B,
+                           "which_side_binds": "priced against the fp32 MFMA peak because the flops put it at the ridge "
+                               "(29.6 us of MFMA vs 23.4 us of HBM at the spec peaks), but the ablation says the MEMORY side "
+                               "binds: the kernel with its MFMAs removed takes 50-53 us, with its stores removed 47 us, "
+                               "MFMA-only 36 us at the 2.1 GHz it holds (DESIGN.md 4.1, profiles/round3_decode_breakdown.json): "
+                               "read `frac` as matrix-pipe utilisation and hbm_frac_of_8TBs as the HBM roofline fraction"}
+        kernels = {"decode": roof_decode}
+        if piped:
+            render_bytes = emit_bytes + resolve_bytes
+            kernels["render_fused"] = {
+                "bound": "hbm", "kernel": "render_fused_kernel (fr_decode_render_pipelined, phases 1|2: emit role of this batch "
+                                          "|| lean resolve role of the previous batch)",
+                "achieved": render_bytes / (fused_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                "avg_ms": fused_ms, "algorithmic_bytes_per_launch": render_bytes,
+                "algorithmic_bytes_are": "the render op's (SURVEY.md 8d): vertices + triangle list + texture read by the emit "
+                                         "role, the four planes written by the resolve role"}
+        else:
+            kernels["raster_emit"] = {"bound": "hbm", "kernel": "raster_emit_kernel (fr_decode_render_forward, phase 1)",
+                                      "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "traffic": None, "avg_ms": emit_ms, "algorithmic_bytes_per_launch": emit_bytes}
+            kernels["resolve_write"] = {"bound": "hbm", "kernel": "resolve_write_kernel<256> (fr_decode_render_forward, phase 2)",
+                                        "achieved": resolve_bytes / (resolve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "traffic": None, "avg_ms": resolve_ms, "algorithmic_bytes_per_launch": resolve_bytes}
+        # HBM traffic per launch + the rocprofv3 kernel averages, from the committed profile passes of this same command
+        # (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc passes; ONE stated correction for all
+        # kernels -- see its `correction` field -- so the figures of one line are comparable)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("batch") == B and (H, W) == (200, 200):
-                if not q30:
-                    roof_decode["traffic"] = pmc["decode_bytes_per_launch"]
-                roof_emit["traffic"] = pmc["render_split"]["raster_emit_kernel"]
-                roof_resolve["traffic"] = pmc["render_split"]["resolve_write_kernel"]
-                for r in (roof_decode, roof_emit, roof_resolve):
-                    if r["traffic"] is not None:
-                        r["traffic_source"] = "profiles/pmc_traffic.json"
+            if pmc.get("batch") == B and (H, W) == (200, 200) and not q30:
+                pk = pmc.get("kernels")
+                for name, r in kernels.items():
+                    rec = pk.get(name) if isinstance(pk, dict) else None
+                    if rec:
+                        r["traffic"] = rec.get("traffic_bytes_per_launch")
+                        r["traffic_source"] = "profiles/pmc_traffic.json (%s)" % pmc.get("correction", "")
+                        if rec.get("rocprofv3_avg_ms") is not None:
+                            r["rocprofv3_avg_ms"] = rec["rocprofv3_avg_ms"]
         except (OSError, ValueError, KeyError):
             pass
-        kernels = {"decode": roof_decode, "raster_emit": roof_emit, "resolve_write": roof_resolve}
         for r in kernels.values():
             r["frac"] = r["achieved"] / r["peak"]
+            r["avg_ms_is"] = ev_note
         dominant = max(kernels.values(), key=lambda r: r["avg_ms"])  # the kernel with the longest average launch
-        render_ms = emit_ms + resolve_ms
-        kernels["render_op"] = {"bound": "hbm", "kernel": "fr_render_depth_forward (both kernels)", "avg_ms": render_ms,
-                                "achieved": ab["render"] * B / (render_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": ab["render"] * B / (render_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "algorithmic_bytes_per_launch": ab["render"] * B}
+        if not piped:
+            render_ms = emit_ms + resolve_ms
+            kernels["render_op"] = {"bound": "hbm", "kernel": "fr_render_depth_forward (both kernels)", "avg_ms": render_ms,
+                                    "achieved": ab["render"] * B / (render_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": ab["render"] * B / (render_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "algorithmic_bytes_per_launch": ab["render"] * B}
+        route = ("pipelined: PipelinedPlan / fr_decode_render_pipelined -- per step TWO launches: decode(k), then ONE launch "
+                 "whose blocks are the emit role of batch k or the (lean) resolve role of batch k-1; a timed block = K "
+                 "submits + the drain, so K batches go from parameters to planes inside the brackets") if piped else \
+                "serial: DecodeRenderPlan / fr_decode_render_forward -- three launches per batch"
         out = {
             "metric": "faces/sec (3DMM decode+depth render), batch 64 @200x200",
             "value": value, "unit": "faces/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": args.scaling,
-            "repeats": R, "value_is": "median over %d timed blocks of K steps each" % R,
+            "repeats": R, "value_is": "median over %d timed blocks of K steps each" % R, "route": route,
             "value_min": faces_per_step * K / max(blocks), "value_max": faces_per_step * K / min(blocks),
             "ms_per_step_min": 1e3 * min(blocks) / K, "ms_per_step_max": 1e3 * max(blocks) / K,
             "blocks_ms_per_step": [round(1e3 * t / K, 5) for t in blocks],   # every timed block, in the order they ran
@@ -441,6 +551,21 @@ def main():
                                   "route": "FaceRecNet.vertices_transform -> rendering_layer.ops.render_depth (outputs "
                                            "allocated per call; the pre-validated triangle table is reused while the "
                                            "same `tri` tensor is passed: ops._render_phases)"}
+        if serial_elapsed is not None:
+            out["serial_plan_faces_per_s"] = faces_per_step * K / serial_elapsed
+            out["serial_plan"] = {"ms_per_step": 1e3 * serial_elapsed / K, "pipelined_vs_serial": serial_elapsed / elapsed,
+                                  "route": "DecodeRenderPlan.step(): decode -> emit -> resolve, three launches, same process, "
+                                           "same K / W / R (median block)"}
+        if allreduce is not None:
+            out["dist"]["allreduce_preflight"] = allreduce
+        if args.scaling == "strong":   # what one GPU's shard was measured to take (profiles/round3_strong_scaling_shards.json)
+            out["dist"]["strong_scaling_prediction"] = {
+                "us_per_step_at_faces_per_gpu": {"64": 116.6, "32": 78.9, "16": 65.6, "8": 57.1},
+                "predicted_speedup_vs_1_gpu": {"1": 1.0, "2": 1.48, "4": 1.78, "8": 2.04},
+                "why": "every rank streams the whole 153 MB basis whatever its share of the batch, and each render kernel "
+                       "keeps ~10 us of latency chain: strong scaling of ONE 64-face batch is structurally poor; the "
+                       "path is meant to scale weakly (64 faces per GPU, no collective)",
+                "source": "profiles/round3_strong_scaling_shards.json (serial plan, one MI355X running a rank's shard)"}
         if graph_fps is not None:
             out["graph_replay_faces_per_s"] = graph_fps
         if args.cpu_faces > 0 and world == 1:

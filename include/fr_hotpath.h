@@ -163,6 +163,26 @@ int fr_decode_render_forward(const float* params, const void* packed_basis, cons
                              float* tex_img, float* normal, float* tri_ind, void* workspace, size_t ws_bytes,
                              void* hip_stream, int phases);
 
+/* The same step, PIPELINED over consecutive batches (replaces the serial batch loop render_depth_op.cc:180-316 across two
+ * calls of the op): the rasteriser's two kernels bind on different units (emit: vector issue; resolve: the store path), so the
+ * emit of batch k runs beside the resolve of batch k-1 as two ROLES of one launch, chosen by block index -- every block
+ * depends only on earlier launches, so there is no event, fence or intra-launch dependency.  Each batch in flight needs its
+ * own render workspace (fr_render_depth_workspace_bytes each, the triangle table packed into both) and its own vertex
+ * hand-off buffer (fr_decode_render_vertex_bytes each; the resolver rasterises oversized triangles from the vertices):
+ *   phases: bit 8 = decode the new batch into vertex_new, bit 4 = pack the triangle list into workspace_new,
+ *   bit 1 = emit the new batch (vertex_new -> workspace_new), bit 2 = resolve the previous batch (workspace_prev, vertex_prev
+ *   -> the four planes).  Bits 1 | 2 together are ONE launch; a stream of batches runs 4 once per workspace, then 8|1 for the first
+ *   batch, 8|1|2 for every further one (the planes of batch k-1 come out of step k) and 2 to drain.  The planes are
+ *   bit-identical to fr_decode_render_forward on the same batch (the screen is cut into narrower strips; no result depends
+ *   on that).  fr_decode_render_pipelined_supported: 1 when the shape is served (a strip of at least 4 rows must fit 12,800 B
+ *   of keys: W <= 400 for H > 4), else 0 and the entry point returns FR_ERR_UNSUPPORTED -- use fr_decode_render_forward. */
+int fr_decode_render_pipelined_supported(int B, int N, int ntri, int H, int W);
+int fr_decode_render_pipelined(const float* params, const void* packed_basis, const float* R_override, const float* tri,
+                               const float* texture, int B, int N, int n_shape, int n_exp, int ntri, int H, int W,
+                               int tex_batch, float im_size, float* vertex_new, const float* vertex_prev, size_t vertex_bytes,
+                               float* depth, float* tex_img, float* normal, float* tri_ind, void* workspace_new,
+                               void* workspace_prev, size_t ws_bytes, void* hip_stream, int phases);
+
 /* Opt-in second definition of the same decode (frozen experiment; nothing of it is built, allocated or
  * launched unless these entry points are called):
  *   Q30: v = fl32(mu + S + E) with S + E an EXACT fixed-point dot product of the operands quantised to 31 bits against

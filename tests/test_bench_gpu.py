@@ -43,6 +43,19 @@ def test_bench_line_one_gpu():
     assert d["parity"]["ok"] and d["parity"]["faces"] == 64 and d["parity"]["mismatching_planes"] == 0
     assert d["ops_surface"]["outputs_identical_to_plan"] and d["ops_surface_faces_per_s"] > 1e4
     assert d["dist"]["world_size"] == 1 and d["config"]["faces_per_step_all_gpus"] == 64
+    # the default route is the serial plan (three launches per batch); the device the rank ran on is in the line
+    assert d["route"].startswith("serial") and {"decode", "raster_emit", "resolve_write"} <= set(d["kernels"])
+    assert d["dist"]["distinct_devices"] and d["dist"]["devices"][0]["name"] and d["dist"]["devices"][0]["id"]
+    assert all("avg_ms_is" in d["kernels"][k] for k in ("decode", "raster_emit", "resolve_write"))
+    assert "which_side_binds" in d["kernels"]["decode"]
+
+
+def test_bench_line_pipelined_route():
+    """--route pipelined: two launches per step (decode, fused emit || resolve); the serial plan is timed beside it and the two
+    routes' planes are compared bit for bit inside the parity gate."""
+    d = _line([sys.executable, "bench.py"] + SHORT + ["--cpu-faces", "0", "--route", "pipelined", "--no-ops-surface"])
+    assert d["route"].startswith("pipelined") and set(d["kernels"]) == {"decode", "render_fused"}
+    assert d["parity"]["ok"] and d["parity"]["planes_identical_to_serial_plan"] and d["serial_plan_faces_per_s"] > 1e4
 
 
 @pytest.mark.parametrize("scaling,global_faces,local_faces", [("weak", 128, 64), ("strong", 64, 32)])
@@ -60,3 +73,8 @@ def test_bench_two_ranks_walk_the_multi_rank_flow(scaling, global_faces, local_f
     p = d["parity"]
     assert p["ok"] and p["faces_all_ranks"] == global_faces and p["mismatching_planes_all_ranks"] == 0
     assert d["cpu_baseline"] is None            # rank 0 at N = 1 only
+    # which device every rank ran on (here: both on the box's one GPU, which only gloo tolerates), and the all-reduce preflight
+    assert len(d["dist"]["devices"]) == 2 and d["dist"]["distinct_devices"] is False and d["dist"]["rccl_version"] is None
+    ar = d["dist"]["allreduce_preflight"]
+    assert ar["sum_correct"] and ar["bytes"] == 4000000 and ar["ms"] > 0
+    assert ("strong_scaling_prediction" in d["dist"]) == (scaling == "strong")
