@@ -488,6 +488,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
 // Development hooks of the emit kernel (tools/emit_probe.hip supplies a stamping policy; the product instantiates NoEmitProbe,
 // whose hooks are empty inlines).
 struct NoEmitProbe {
+    static constexpr int abl = 0;   // tools/emit_probe.hip: ablation level (the kernel returns at cut point `abl`); 0 = the product
     __device__ __forceinline__ void begin() {}
     template <int ID> __device__ __forceinline__ void stamp() {}
     __device__ __forceinline__ void finish(int) {}
@@ -517,6 +518,7 @@ __device__ __forceinline__ void emit_body(const RenderArgs& a, const int lid, un
     uint32_t* const cnt = reinterpret_cast<uint32_t*>(lds + EMIT_LDS_CNT);
     unsigned long long& qn2 = *reinterpret_cast<unsigned long long*>(lds + EMIT_LDS_QN2);
     const int tid = threadIdx.x;
+    if constexpr (PR::abl == 1) return;   // (ablation: empty workgroups)
     const int b = a.nseg_magic ? (int)__umulhi((uint32_t)lid, a.nseg_magic) : lid / a.nseg;  // lid / nseg
     const int seg = lid - b * a.nseg;
     const int S = a.strips;
@@ -546,11 +548,22 @@ __device__ __forceinline__ void emit_body(const RenderArgs& a, const int lid, un
             e[u] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.tri4) + (size_t)((uint32_t)min(t, ntri - 1) << 4));
             valid[u] = ((int)(tid < EMIT_ACTIVE) & (int)(t < ntri) & e[u].w & table_ok) != 0;
         }
+        if constexpr (PR::abl == 2) {   // (ablation: the table loads only)
+            if (e[0].x + e[1].y == 0x7fffffff) qd[tid].x = 1;
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
             x1[u] = ld_boff(vx, e[u].x); x2[u] = ld_boff(vx, e[u].y); x3[u] = ld_boff(vx, e[u].z);
             y1[u] = ld_boff(vy, e[u].x); y2[u] = ld_boff(vy, e[u].y); y3[u] = ld_boff(vy, e[u].z);
             z1[u] = ld_boff(vz, e[u].x); z2[u] = ld_boff(vz, e[u].y); z3[u] = ld_boff(vz, e[u].z);
+        }
+        if constexpr (PR::abl == 3) {   // (ablation: table + the eighteen gathers, nothing computed)
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < TPT; u++) acc += ((x1[u] + x2[u]) + x3[u]) + ((y1[u] + y2[u]) + y3[u]) + ((z1[u] + z2[u]) + z3[u]);
+            if (acc == 1.2345e30f) qd[tid].x = 1;
+            return;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // counters zeroed (first used by the compaction below)
         pr.template stamp<0>();
@@ -626,6 +639,7 @@ __device__ __forceinline__ void emit_body(const RenderArgs& a, const int lid, un
         }
     }
     pr.template stamp<2>();   // compaction done
+    if constexpr (PR::abl == 5) return;   // (ablation: phase A complete)
     __syncthreads();
     pr.template stamp<3>();
 
@@ -746,6 +760,7 @@ __device__ __forceinline__ void emit_body(const RenderArgs& a, const int lid, un
         qd[sl].x = tag;
     }
     pr.template stamp<4>();   // phase B done
+    if constexpr (PR::abl == 6) return;   // (ablation: phases A + B)
     __syncthreads();
     pr.template stamp<5>();
     // ---------------- phase C: bucket offsets, records out ----------------
@@ -762,6 +777,7 @@ __device__ __forceinline__ void emit_body(const RenderArgs& a, const int lid, un
     }
     __syncthreads();
     pr.template stamp<6>();
+    if constexpr (PR::abl == 7) return;   // (ablation: everything but the record stores)
     uint4* R = a.recs + ((size_t)b * a.nseg + seg) * (2 * SEG);
     for (int qi = tid; qi < nq; qi += EMIT_BLOCK) {
         const int sl = qi < nqf ? qi : SEG - 1 - (qi - nqf);

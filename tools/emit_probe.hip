@@ -18,6 +18,7 @@ __device__ __forceinline__ unsigned long long estamp() {
     return t;
 }
 struct EmitStampProbe {
+    static constexpr int abl = 0;
     unsigned long long t[8];
     __device__ __forceinline__ void begin() {
 #pragma unroll
@@ -36,6 +37,44 @@ struct EmitStampProbe {
         }
     }
 };
+
+// ablated builds of the emit kernel: the kernel returns at cut point LEVEL (1 = empty workgroups, 2 = table loads, 3 = + the
+// eighteen gathers, 5 = + bbox / pre-cull + compaction (phase A complete), 6 = + phase B, 7 = + bucket scan, 0 = all)
+template <int LEVEL>
+struct EmitAblate {
+    static constexpr int abl = LEVEL;
+    __device__ __forceinline__ void begin() {}
+    template <int ID> __device__ __forceinline__ void stamp() {}
+    __device__ __forceinline__ void finish(int) {}
+};
+template <int LEVEL>
+static void launch_ablate(const fr::RenderArgs& a, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((fr::raster_emit_kernel<EmitAblate<LEVEL>>), dim3(grid), dim3(fr::EMIT_BLOCK), 0, st, a);
+}
+extern "C" int fr_probe_emit_ablate(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
+                                    int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
+                                    void* workspace, size_t ws_bytes, long long vpitch, int level, void* hip_stream) {
+    using namespace fr;
+    RenderArgs a;
+    RenderGeom g;
+    bool binned = false;
+    int rc = prepare_render(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr, nullptr,
+                            nullptr, workspace, ws_bytes, vpitch, a, g, &binned);
+    if (rc != FR_OK || !binned) return rc ? rc : -100;
+    const unsigned grid = (unsigned)((long long)B * g.nseg);
+    hipStream_t st = (hipStream_t)hip_stream;
+    switch (level) {
+        case 0: hipLaunchKernelGGL(raster_emit_kernel<NoEmitProbe>, dim3(grid), dim3(EMIT_BLOCK), 0, st, a); break;
+        case 1: launch_ablate<1>(a, grid, st); break;
+        case 2: launch_ablate<2>(a, grid, st); break;
+        case 3: launch_ablate<3>(a, grid, st); break;
+        case 5: launch_ablate<5>(a, grid, st); break;
+        case 6: launch_ablate<6>(a, grid, st); break;
+        case 7: launch_ablate<7>(a, grid, st); break;
+        default: return -101;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : FR_ERR_LAUNCH;
+}
 
 // the PRODUCT emit kernel launched with `extra_lds` bytes of (unused) dynamic LDS: limits the workgroups resident per CU
 // (160 KiB / (20.4 KiB + extra)) -- what a kernel fused with the resolver's larger footprint would run at
