@@ -109,6 +109,7 @@ enum Opt {
     OPT_DECODE_STORE,   // FR_DECODE_STORE   0 = default epilogue, 1 = transposed accumulators + one dword per lane (A/B knob)
     OPT_FUSED_ORDER,    // FR_FUSED_ORDER    resolve blocks of the fused launch: 0 = spread evenly (default), 1 = first, 2 = last
     OPT_FUSED_ALONE,    // FR_FUSED_ALONE    1 = a lone emit / resolve phase of the pipelined entry also runs through the fused kernel (probe)
+    OPT_BWD_CHUNKS,     // FR_BWD_CHUNKS     row chunks (workgroups, partial slabs) of the packed decode-backward GEMM: 256 (default: one workgroup per CU), 1 .. 512
     OPT_COUNT
 };
 int opt(Opt o);

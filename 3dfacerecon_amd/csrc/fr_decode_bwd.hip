@@ -306,9 +306,9 @@ __global__ __launch_bounds__(256) void bwd_pack_kernel(const float* __restrict__
 }
 
 #define FRB_LD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
-constexpr int BR = 3;   // ring depth in 16-row blocks: 24 fragment loads (24 KiB) in flight per wave
-
-template <int NB>
+// BR: ring depth in 16-row blocks: 8 BR fragment loads (BR x 8 KiB) in flight per wave.  (Round 4, same-process A/B at one
+// workgroup per CU: BR = 4 and 5 -- 32 / 40 KiB in flight per wave, 200 / 232 VGPRs -- measured 96-97 us against 96 at 64 faces.)
+template <int NB, int BR = 3>
 __global__ __launch_bounds__(BW_MAXWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void bwd_gemm_ring_kernel(BwdArgs a) {
     const int lane = threadIdx.x & 63;
@@ -348,9 +348,9 @@ void bwd_gemm_ring_kernel(BwdArgs a) {
 #pragma unroll
         for (int d = 0; d < BR; d++) {
             // the 8 loads of ring slot d are the oldest outstanding ones: all but the 8 (BR - 1) youngest must be back
-            asm volatile("s_waitcnt vmcnt(16)" : "+v"(ra[d][0]), "+v"(ra[d][1]), "+v"(ra[d][2]), "+v"(ra[d][3]), "+v"(rbv[d][0]),
-                         "+v"(rbv[d][1]), "+v"(rbv[d][2]), "+v"(rbv[d][3]));
-            static_assert(BR == 3, "the counted wait above is written for three ring slots of eight loads");
+            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ra[d][0]), "+v"(ra[d][1]), "+v"(ra[d][2]), "+v"(ra[d][3]), "+v"(rbv[d][0]),
+                         "+v"(rbv[d][1]), "+v"(rbv[d][2]), "+v"(rbv[d][3]) : "n"(8 * (BR - 1)));
+            static_assert(8 * (BR - 1) <= 63, "vmcnt is a 6-bit counter");
             if (rb0 + d < rb_end) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)        // k-step: rows 16 rb + 4 j .. + 3, ascending
@@ -480,10 +480,23 @@ static BwdGeom bwd_geom(int N, int ns = 199, int ne = 29) {
     g.sbs = (ns + 15) / 16;
     g.sbt = g.sbs + (ne + 15) / 16;
     g.waves_p = (g.sbt + 3) / 4;
-    g.rb_per_block = (int)((g.rbt + 511) / 512);
+    // row chunks of the packed GEMM (one workgroup and one partial slab each): FR_BWD_CHUNKS, at most 512 (the slab space is
+    // sized for 512 whatever the knob says, so that a workspace sized before the knob changed still fits)
+    // Default 256 = one four-wave workgroup per CU of an MI355X (a constant, not the device's CU count: the chunking fixes the
+    // association of the sums, so the gradient's bits must not depend on the part).  Round 4, same-process A/B through the
+    // autograd surface: 512 chunks (two workgroups per CU, round 3) 108.2 us, 256 chunks 96.0 us at 64 faces; 80.2 -> 76.4 us
+    // at 32; 384 and 128 are slower than both (uneven CU load / too little in flight).  Half the slabs also halve the
+    // reduce kernel's reads.
+    int chunks = opt(OPT_BWD_CHUNKS);
+    if (chunks < 1 || chunks > 512) chunks = 256;
+    g.rb_per_block = (int)((g.rbt + chunks - 1) / chunks);
     if (g.rb_per_block < 1) g.rb_per_block = 1;
     g.gemm_blocks_p = g.rbt > 0 ? (g.rbt + g.rb_per_block - 1) / g.rb_per_block : 0;
-    g.slab_bytes_p = (size_t)g.gemm_blocks_p * 64 * g.waves_p * 64 * sizeof(float);
+    {
+        const int rpb512 = g.rbt > 512 ? (g.rbt + 511) / 512 : 1;
+        const int blocks512 = g.rbt > 0 ? (g.rbt + rpb512 - 1) / rpb512 : 0;
+        g.slab_bytes_p = (size_t)blocks512 * 64 * g.waves_p * 64 * sizeof(float);
+    }
     g.at_bytes = (size_t)g.rbt * g.sbt * 64 * sizeof(float4);
     g.pose_bytes = (((size_t)g.pre_blocks * 64 * 4 * sizeof(float)) + 15) & ~(size_t)15;
     g.slab_bytes = (size_t)g.gemm_blocks * 64 * bw_waves(ns, ne) * 64 * sizeof(float);

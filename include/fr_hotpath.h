@@ -45,6 +45,11 @@ const char* fr_strerror(int code);
  *   FR_RESOLVE_OPT (2 = default: wave-local front for 256-thread bins | 1 = block-wide list, single-trip bins keep their
  *   records in registers | 0 = two-pass resolver)   FR_EMIT_FILTER (bits 0-1, default 3)   FR_RENDER_IMPL (0 | 1 = "scan": strip-scan fallback)
  *   FR_RESOLVE_BLOCK (0 = auto | 256 | 512 | 1024)   FR_RENDER_ROWS (0 = auto | rows per screen strip)
+ *   FR_DECODE_STORE (0 | 1 = transposed accumulators, one dword per lane per store: measured +1.1 us, A/B only)
+ *   FR_FUSED_ORDER (resolve blocks of the pipelined entry's fused launch: 0 = spread evenly | 1 = first | 2 = last)
+ *   FR_FUSED_ALONE (0 | 1 = probe: a lone emit / resolve phase of the pipelined entry also runs through the fused kernel)
+ *   FR_BWD_CHUNKS (row chunks of the packed decode-backward GEMM: 256 = default | 1 .. 512; changes the association of the
+ *   partial sums, i.e. the gradient's last bits -- every other knob leaves every result bit unchanged)
  * None of them changes a result bit (tests/test_render_gpu.py, tests/test_decode_gpu.py hold every setting to the oracle).
  * Returns FR_OK or FR_ERR_INVALID_ARG (unknown name). */
 int fr_set_option(const char* name, int value);
