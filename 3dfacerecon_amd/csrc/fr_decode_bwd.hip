@@ -7,7 +7,8 @@
 //   dv      = (f R)^T dq ;  d alpha = pc_shape^T dv ;  d beta = pc_exp^T dv          (:153-159)
 //   d angles = 0: R comes out of tf.py_func (:150), which has no gradient in the reference.
 //
-// How: three launches, no float atomics (bit-reproducible):
+// How (reference-layout entry point; the packed entry point runs bwd_fused_kernel + bwd_reduce_kernel: see there): three
+// launches, no float atomics (bit-reproducible):
 //   bwd_prepass_kernel  elementwise: dq -> dv, written transposed into MFMA B-fragment order dvT4[row][16][4]
 //                       (LDS tile transpose so both the read of g and the write of dvT4 are coalesced), plus
 //                       per-workgroup partial sums for d t3d and d f;
@@ -46,10 +47,12 @@ struct BwdArgs {
     int pre_blocks, gemm_blocks, rows_per_block;
     float im_size;
     // K-major packed image (fr_decode_backward_pack_basis) and its geometry; null: the reference-layout kernel runs
-    const float4* At;        // [row blocks][slot blocks][64 lanes] float4
+    const float4* At;        // packed image [vertex groups of 16][3 coordinates][slot blocks][64 lanes] float4 (bwd_pack_kernel)
     int sbt, sbs;            // slot blocks of 16 coefficients in all / of the shape basis (expression blocks follow)
-    int rbt, rb_per_block;   // row blocks of 16 rows in all / per gemm workgroup
+    int rbt, rb_per_block;   // reference-layout path: 16-row blocks in all / per gemm workgroup.  Packed path (bwd_fused_kernel):
+                             // vertex groups of 16 in all / per workgroup
     int exp_slot0;           // first coefficient slot of the expression basis in the slabs
+    int nslots;              // coefficient slots per partial slab (64 per wave of the GEMM workgroup)
 };
 
 __device__ __forceinline__ void bwd_rotation(const BwdArgs& a, int b, float* R9) {
@@ -255,8 +258,7 @@ __global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_gemm_kernel(BwdArgs a) {
         consume(dv, av);
     }
     // D^T tile of MFMA i: row m = 4*(lane>>4) + reg is coefficient slot 64*wave + 4*m + i, column (batch within block) = lane & 15
-    const int nslots = 64 * (int)(blockDim.x >> 6);
-    float* slab = a.slab + (size_t)blockIdx.x * nslots * 64;
+    float* slab = a.slab + (size_t)blockIdx.x * a.nslots * 64;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -280,24 +282,29 @@ __global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_gemm_kernel(BwdArgs a) {
 // counted.  Accumulation order per output: rows ascending within the workgroup's row range (as above); the partial
 // slabs are summed by bwd_reduce_kernel in its fixed order.
 __global__ __launch_bounds__(256) void bwd_pack_kernel(const float* __restrict__ pc_shape, const float* __restrict__ pc_exp,
-                                                       int N, int ns, int ne, int sbs, int sbt, long long rbt,
+                                                       int N, int ns, int ne, int sbs, int sbt, long long ngroups,
                                                        float4* __restrict__ At) {
-    const long long rows = 3ll * N;
-    const long long total = rbt * sbt * 64;
+    // image [vertex group of 16][coordinate][16-coefficient block][lane] float4, element j = basis[c N + 16 grp + 4 j + (lane >> 4)]
+    // [16 sb + (lane & 15)], zero padded: a vertex group's three 16-row blocks (x, y, z rows of the SAME sixteen vertices) sit
+    // side by side, so that the workgroup that multiplies them can form their dv rows from ONE tile of the incoming gradient
+    const long long total = ngroups * 3 * sbt * 64;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
-        const long long q = i >> 6;
+        long long q = i >> 6;
         const int sb = (int)(q % sbt);
-        const long long rb = q / sbt;
+        q /= sbt;
+        const int c = (int)(q % 3);
+        const long long grp = q / 3;
         const int slot = 16 * sb + (lane & 15);
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const long long row = 16 * rb + 4 * j + (lane >> 4);
+            const long long pv = 16 * grp + 4 * j + (lane >> 4);
             float x = 0.f;
-            if (row < rows) {
-                if (sb < sbs) { if (slot < ns) x = pc_shape[(size_t)row * ns + slot]; }
-                else { const int c = slot - 16 * sbs; if (c < ne) x = pc_exp[(size_t)row * ne + c]; }
+            if (pv < N) {
+                const size_t row = (size_t)c * N + pv;
+                if (sb < sbs) { if (slot < ns) x = pc_shape[row * ns + slot]; }
+                else { const int cc = slot - 16 * sbs; if (cc < ne) x = pc_exp[row * ne + cc]; }
             }
             v[j] = x;
         }
@@ -306,74 +313,211 @@ __global__ __launch_bounds__(256) void bwd_pack_kernel(const float* __restrict__
 }
 
 #define FRB_LD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
-// BR: ring depth in 16-row blocks: 8 BR fragment loads (BR x 8 KiB) in flight per wave.  (Round 4, same-process A/B at one
-// workgroup per CU: BR = 4 and 5 -- 32 / 40 KiB in flight per wave, 200 / 232 VGPRs -- measured 96-97 us against 96 at 64 faces.)
-template <int NB, int BR = 3>
-__global__ __launch_bounds__(BW_MAXWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void bwd_gemm_ring_kernel(BwdArgs a) {
-    const int lane = threadIdx.x & 63;
+// ---- the fused backward: gradient tile -> dv rows (LDS) -> MFMA reduction, one launch ------------------------------------------
+// Round 3 ran a prepass (g, vertex_proj -> dv rows in B-fragment order + the pose partial sums: 123 MB moved, 27.6 us) and then
+// the reduction (153 MB of basis + the 41 MB of dv rows again).  Here ONE workgroup per CU walks its vertex groups of 16; per
+// group its 256 staging threads -- thread = (batch column b, vertex quad q) -- load the 16 x 64 tile of g and of vertex_proj
+// (six 16-byte loads per thread, inline asm, in the same counted-wait stream as the basis fragments), form the group's
+// three dv row blocks  dv = (f R)^T dq  and the d t3d / d f partial sums in registers, and park the dv rows in LDS in MFMA
+// B-fragment order (double buffered; ONE LDS-only barrier per group); the waves then multiply the group's three basis row
+// blocks (twelve 1 KiB fragments per wave, two groups in flight) against them.  dv never exists in global memory: g and
+// vertex_proj are read once, the 41 MB write + re-read and the prepass launch are gone.
+// Summation order: per output, groups ascending, x / y / z row block, k-step -- fixed by the chunking (FR_BWD_CHUNKS) alone.
+template <int NB>
+__global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_fused_kernel(BwdArgs a) {
+    __shared__ float Mt[64][13];                                            // f*R (9), t (3), 1/f or 0
+    __shared__ __attribute__((aligned(16))) float4 dvL[2][3][4][64];        // [buffer][coordinate][k-step][lane] (mb in .xyzw)
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nd = FR_N_POSE + a.ns + a.ne;
+    const int N = a.N;
+    if (tid < 64) {
+        float m[13];
+#pragma unroll
+        for (int i = 0; i < 13; i++) m[i] = 0.f;
+        if (tid < a.nbatch) {
+            const float* pr = a.params + (size_t)(a.b0 + tid) * nd;
+            float R[9];
+            bwd_rotation(a, tid, R);
+            const float f = pr[6];
+#pragma unroll
+            for (int i = 0; i < 9; i++) m[i] = f * R[i];
+            m[9] = pr[3]; m[10] = pr[4]; m[11] = pr[5];
+            m[12] = (f != 0.0f) ? 1.0f / f : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 13; i++) Mt[tid][i] = m[i];
+    }
+    __syncthreads();
+    // staging role (threads 0..255): batch column sb_ = tid >> 2 (its 16-column block is the wave index), vertex quad q
+    const bool stager = tid < 256;
+    const int sb_ = (tid >> 2) & 63, q = tid & 3;
+    const bool blive = stager && sb_ < a.nbatch;
+    float m[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) m[i] = Mt[sb_][i];
+    const int bc = min(sb_, a.nbatch - 1);   // (dead columns load a live column's tile and discard it)
+    const float* gx = a.g + (size_t)(a.b0 + bc) * 3 * N + 4 * q;
+    const float* vx = a.vproj + (size_t)(a.b0 + bc) * 3 * N + 4 * q;
+    // MFMA role: this wave's four 16-coefficient blocks
     const int kq = lane >> 4, jn = lane & 15;
     const int sbt = a.sbt;
-    const int sb0 = 4 * wave;                              // this wave's four 16-coefficient blocks
-    const int nsb = min(4, sbt - sb0);                     // live ones (wave-uniform, >= 1)
-    const long long rb_begin = (long long)blockIdx.x * a.rb_per_block;
-    const long long rb_end = min((long long)a.rbt, rb_begin + a.rb_per_block);
+    const int sb0 = 4 * wave;
+    const int nsb = max(0, min(4, sbt - sb0));           // live ones (wave-uniform; 0: a staging-only wave)
+    const long long g_begin = (long long)blockIdx.x * a.rb_per_block;              // (rb_per_block = vertex groups per workgroup)
+    const long long g_end = min((long long)a.rbt, g_begin + a.rb_per_block);       // (rbt = vertex groups in all)
+    const int n = (int)(g_end - g_begin);
     f32x4 acc[4][NB];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int mb = 0; mb < NB; mb++) acc[i][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 ra[BR][4], rbv[BR][4];   // ring: the row block's A fragments (one per coefficient block) and dv fragments (one per k-step)
-    // fragment addresses of row block rb (clamped: a slot past the end re-requests the last block and is never consumed;
-    // a dead coefficient block re-requests block sbt - 1)
-    auto request = [&](int d, long long rb) {
-        const long long rbc = min(rb, (long long)a.rbt - 1);
-        const float4* ab = a.At + ((size_t)rbc * sbt) * 64 + lane;
-        const float4* bb = a.dvT4 + (size_t)rbc * 256 + lane;
+    f32x4 ra[2][3][4];     // basis fragments of two groups in flight: [slot][coordinate][coefficient block]
+    f32x4 tg[3], tv[3];    // the tile: g and vertex_proj, x / y / z rows, this thread's four vertices
+    float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;   // pose partial sums of this thread's column: d t3d (3), sum (q - t) . dq
+    // requests (a group past the end re-requests the last one and is never consumed; a dead coefficient block re-requests the
+    // image's last block: every wave issues the same number of loads in the same order, which is what the counted waits count)
+    auto req_tile = [&](long long grp) {
+        const long long gc = min(grp, (long long)a.rbt - 1);
+        // (the LAST group's vertices may end before its sixteen: its loads are clamped to stay inside the rows; the values
+        // of the missing vertices are zeroed by the mask below)
+        const long long p0 = min(16 * gc, (long long)max(N - 16, 0));
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float* pg = gx + (size_t)c * N + p0;
+            const float* pv = vx + (size_t)c * N + p0;
+            FRB_LD(tg[c], pg);
+            FRB_LD(tv[c], pv);
+        }
+    };
+    auto req_basis = [&](int d, int c, long long grp) {
+        const long long gc = min(grp, (long long)a.rbt - 1);
+        const float4* ab = a.At + ((size_t)(gc * 3 + c) * sbt) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const float4* p = ab + (size_t)min(sb0 + i, sbt - 1) * 64;
-            FRB_LD(ra[d][i], p);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float4* p = bb + (size_t)j * 64;
-            FRB_LD(rbv[d][j], p);
+            FRB_LD(ra[d][c][i], p);
         }
     };
+    // tile -> dv rows of group grp into LDS buffer `buf` + the pose partial sums (tile registers must have arrived)
+    auto stage = [&](long long grp, int buf) {
+        const long long p0 = min(16 * grp, (long long)max(N - 16, 0));   // first vertex the tile was loaded from
+        const int shift = (int)(16 * grp - p0);                              // > 0 only in a clamped last group
+        float dvr[3][4];
 #pragma unroll
-    for (int d = 0; d < BR; d++) request(d, rb_begin + d);
-    for (long long rb0 = rb_begin; rb0 < rb_end; rb0 += BR) {
-#pragma unroll
-        for (int d = 0; d < BR; d++) {
-            // the 8 loads of ring slot d are the oldest outstanding ones: all but the 8 (BR - 1) youngest must be back
-            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ra[d][0]), "+v"(ra[d][1]), "+v"(ra[d][2]), "+v"(ra[d][3]), "+v"(rbv[d][0]),
-                         "+v"(rbv[d][1]), "+v"(rbv[d][2]), "+v"(rbv[d][3]) : "n"(8 * (BR - 1)));
-            static_assert(8 * (BR - 1) <= 63, "vmcnt is a 6-bit counter");
-            if (rb0 + d < rb_end) {
-#pragma unroll
-                for (int j = 0; j < 4; j++)        // k-step: rows 16 rb + 4 j .. + 3, ascending
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (i < nsb) {
-#pragma unroll
-                            for (int mb = 0; mb < NB; mb++)
-                                acc[i][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[d][i][j], rbv[d][j][mb], acc[i][mb], 0, 0, 0);
-                        }
+        for (int r = 0; r < 4; r++) {
+            // vertex of this slot: 16 grp + 4 q + r; it sits at tile position 4 q + r + shift (past 16: it does not exist)
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            bool ok = blive && (16 * grp + 4 * q + r) < N;
+            if (shift == 0) {
+                g0 = tg[0][r]; g1 = tg[1][r]; g2 = tg[2][r]; v0 = tv[0][r]; v1 = tv[1][r]; v2 = tv[2][r];
+            } else {
+                ok = false;   // (clamped group: taken by the slow path below)
             }
-            request(d, rb0 + d + BR);
+            const float dq0 = ok ? g0 : 0.f, dq1 = ok ? -g1 : 0.f, dq2 = ok ? g2 : 0.f;
+            const float q0 = v0 - m[9], q1 = ((a.im_size - 1.0f) - v1) - m[10], q2 = v2 - m[11];
+            const float fs = ok ? __builtin_fmaf(q2, dq2, __builtin_fmaf(q1, dq1, q0 * dq0)) : 0.f;
+            ps0 += dq0; ps1 += dq1; ps2 += dq2; ps3 += fs;
+            // (a slot without a vertex or a column without a face is exactly zero -- not 0 * m, which an infinite f would turn
+            // into a NaN that the zero-padded basis rows then spread over the whole sum)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                dvr[c][r] = ok ? __builtin_fmaf(m[6 + c], dq2, __builtin_fmaf(m[3 + c], dq1, m[c] * dq0)) : 0.f;
+        }
+        if (shift != 0 && stager) {   // the one clamped group of the launch: guarded scalar loads (drains the wave's loads once)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const long long pvx = 16 * grp + 4 * q + r;
+                float dq0 = 0.f, dq1 = 0.f, dq2 = 0.f, fs = 0.f;
+                if (blive && pvx < N) {
+                    const float* gb = a.g + (size_t)(a.b0 + bc) * 3 * N + pvx;
+                    const float* vb = a.vproj + (size_t)(a.b0 + bc) * 3 * N + pvx;
+                    dq0 = gb[0]; dq1 = -gb[N]; dq2 = gb[2 * (size_t)N];
+                    const float q0 = vb[0] - m[9], q1 = ((a.im_size - 1.0f) - vb[N]) - m[10], q2 = vb[2 * (size_t)N] - m[11];
+                    fs = __builtin_fmaf(q2, dq2, __builtin_fmaf(q1, dq1, q0 * dq0));
+                }
+                ps0 += dq0; ps1 += dq1; ps2 += dq2; ps3 += fs;
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    dvr[c][r] = (blive && pvx < N) ? __builtin_fmaf(m[6 + c], dq2, __builtin_fmaf(m[3 + c], dq1, m[c] * dq0)) : 0.f;
+            }
+        }
+        if (stager) {
+            // B fragment of k-step j = q: lane 16 r + (column & 15) holds dv[row 4 q + r][column], component = column >> 4
+            float* base = reinterpret_cast<float*>(&dvL[buf][0][q][0]) + (size_t)(sb_ & 15) * 4 + (sb_ >> 4);
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) base[(size_t)c * (4 * 64 * 4) + (size_t)(16 * r) * 4] = dvr[c][r];
+        }
+    };
+    if (n > 0) {
+        // prologue: group 0's tile and basis fragments, its dv rows into buffer 0; then group 1's tile and fragments
+        req_tile(g_begin);
+#pragma unroll
+        for (int c = 0; c < 3; c++) req_basis(0, c, g_begin);
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(tg[0]), "+v"(tg[1]), "+v"(tg[2]), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]));
+        stage(g_begin, 0);
+        req_tile(g_begin + 1);
+#pragma unroll
+        for (int c = 0; c < 3; c++) req_basis(1, c, g_begin + 1);
+        // (two trips per loop pass, fully unrolled: the ring slot / LDS buffer index d is a compile-time constant -- indexed at
+        // run time the fragment ring lands in scratch memory; a trip past the last group still waits, requests and meets the
+        // barrier like the others -- every wave runs the same count -- and only skips the staging and the MFMAs)
+        for (int i0 = 0; i0 < n; i0 += 2) {
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const int i = i0 + d;
+                const long long grp = g_begin + i;
+                // tile of group i + 1 (behind it: the twelve fragments of group i + 1)
+                asm volatile("s_waitcnt vmcnt(12)" : "+v"(tg[0]), "+v"(tg[1]), "+v"(tg[2]), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]));
+                // every wave has finished reading buffer d ^ 1 (group i - 1); buffer d (group i, written last trip) is published
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (i + 1 < n) stage(grp + 1, d ^ 1);
+                req_tile(grp + 2);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    // the four fragments of (group i, coordinate c): 32 younger loads are in flight behind them
+                    asm volatile("s_waitcnt vmcnt(32)" : "+v"(ra[d][c][0]), "+v"(ra[d][c][1]), "+v"(ra[d][c][2]), "+v"(ra[d][c][3]));
+                    if (nsb > 0 && i < n) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {          // k-step: rows 4 j .. 4 j + 3 of the row block, ascending
+                            const float4 bv = dvL[d][c][j][lane];
+                            const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                            for (int ii = 0; ii < 4; ii++)
+                                if (ii < nsb) {
+#pragma unroll
+                                    for (int mb = 0; mb < NB; mb++)
+                                        acc[ii][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[d][c][ii][j], bq[mb], acc[ii][mb], 0, 0, 0);
+                                }
+                        }
+                    }
+                    req_basis(d, c, grp + 2);
+                }
+            }
+        }
+#pragma unroll
+        for (int dd = 0; dd < 2; dd++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[dd][c][0]), "+v"(ra[dd][c][1]), "+v"(ra[dd][c][2]), "+v"(ra[dd][c][3]));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(tg[0]), "+v"(tg[1]), "+v"(tg[2]), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]));
+    }
+    // pose partial sums: the four vertex quads of a column are the four lanes of a DPP quad -- (q0 + q1) + (q2 + q3), fixed
+    if (stager) {
+#define FR_QUAD_SUM(x)                                                                                                         \
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true)); /* quad_perm [1,0,3,2] */       \
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true)); /* quad_perm [2,3,0,1] */
+        FR_QUAD_SUM(ps0) FR_QUAD_SUM(ps1) FR_QUAD_SUM(ps2) FR_QUAD_SUM(ps3)
+#undef FR_QUAD_SUM
+        if (q == 0) {
+            float* pp = a.pose_part + ((size_t)blockIdx.x * 64 + sb_) * 4;
+            pp[0] = ps0; pp[1] = ps1; pp[2] = ps2; pp[3] = ps3 * m[12];
         }
     }
-#pragma unroll
-    for (int d = 0; d < BR; d++)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[d][0]), "+v"(ra[d][1]), "+v"(ra[d][2]), "+v"(ra[d][3]), "+v"(rbv[d][0]),
-                     "+v"(rbv[d][1]), "+v"(rbv[d][2]), "+v"(rbv[d][3]));
     // D tile of coefficient block i: row m = 4 * (lane >> 4) + reg is slot 64 wave + 16 i + m, column (batch in block) = lane & 15
-    // (staging the tile through LDS so that a store instruction writes four whole 256-byte slab rows instead of four 64-byte
-    // pieces measured no faster: 59.2 vs 58.0 us at 64 faces -- the store tail is not what bounds the kernel)
-    const int nslots = 64 * (int)(blockDim.x >> 6);
-    float* slab = a.slab + (size_t)blockIdx.x * nslots * 64;
+    float* slab = a.slab + (size_t)blockIdx.x * a.nslots * 64;
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (i < nsb) {
@@ -397,7 +541,7 @@ constexpr int RED_WAVES = 16;
 __global__ __launch_bounds__(RED_WAVES * 64) void bwd_reduce_kernel(BwdArgs a) {
     __shared__ float part[RED_WAVES][64];
     const int nd = FR_N_POSE + a.ns + a.ne;
-    const int nslots = a.At ? 64 * ((a.sbt + 3) / 4) : 64 * bw_waves(a.ns, a.ne);
+    const int nslots = a.nslots;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int what = blockIdx.x, b = lane;  // i = what * 64 + b
     const float* src;
@@ -462,6 +606,7 @@ struct BwdGeom {
     size_t dv_bytes, pose_bytes, slab_bytes;
     // packed-image variant
     int sbs, sbt, rbt, rb_per_block, gemm_blocks_p, waves_p;
+    int ngroups, groups_per_block, block_waves_p;   // packed path: vertex groups of 16, per workgroup; waves per workgroup
     size_t slab_bytes_p, at_bytes;
 };
 static BwdGeom bwd_geom(int N, int ns = 199, int ne = 29) {
@@ -480,25 +625,26 @@ static BwdGeom bwd_geom(int N, int ns = 199, int ne = 29) {
     g.sbs = (ns + 15) / 16;
     g.sbt = g.sbs + (ne + 15) / 16;
     g.waves_p = (g.sbt + 3) / 4;
-    // row chunks of the packed GEMM (one workgroup and one partial slab each): FR_BWD_CHUNKS, at most 512 (the slab space is
-    // sized for 512 whatever the knob says, so that a workspace sized before the knob changed still fits)
-    // Default 256 = one four-wave workgroup per CU of an MI355X (a constant, not the device's CU count: the chunking fixes the
-    // association of the sums, so the gradient's bits must not depend on the part).  Round 4, same-process A/B through the
-    // autograd surface: 512 chunks (two workgroups per CU, round 3) 108.2 us, 256 chunks 96.0 us at 64 faces; 80.2 -> 76.4 us
-    // at 32; 384 and 128 are slower than both (uneven CU load / too little in flight).  Half the slabs also halve the
-    // reduce kernel's reads.
+    // Packed path: row chunks = workgroups = partial slabs: FR_BWD_CHUNKS, at most 512.  Default 256 = one four-wave workgroup per
+    // CU of an MI355X (a constant, not the device's CU count: the chunking fixes the association of the sums, so the gradient's
+    // bits must not depend on the part).  Round 4, same-process A/B through the autograd surface (round 3's prepass + ring GEMM):
+    // 512 chunks 108.2 us, 256 chunks 96.0 us at 64 faces; 80.2 -> 76.4 us at 32; 384 and 128 are slower than both.  The slab /
+    // partial space is sized for 512 chunks whatever the knob says, so that a workspace sized before it changed still fits.
     int chunks = opt(OPT_BWD_CHUNKS);
     if (chunks < 1 || chunks > 512) chunks = 256;
-    g.rb_per_block = (int)((g.rbt + chunks - 1) / chunks);
-    if (g.rb_per_block < 1) g.rb_per_block = 1;
-    g.gemm_blocks_p = g.rbt > 0 ? (g.rbt + g.rb_per_block - 1) / g.rb_per_block : 0;
+    g.ngroups = (N + 15) / 16;
+    g.groups_per_block = (g.ngroups + chunks - 1) / chunks;
+    if (g.groups_per_block < 1) g.groups_per_block = 1;
+    g.gemm_blocks_p = g.ngroups > 0 ? (g.ngroups + g.groups_per_block - 1) / g.groups_per_block : 0;
+    g.block_waves_p = g.waves_p < 4 ? 4 : g.waves_p;   // (the 256 staging threads of bwd_fused_kernel)
     {
-        const int rpb512 = g.rbt > 512 ? (g.rbt + 511) / 512 : 1;
-        const int blocks512 = g.rbt > 0 ? (g.rbt + rpb512 - 1) / rpb512 : 0;
-        g.slab_bytes_p = (size_t)blocks512 * 64 * g.waves_p * 64 * sizeof(float);
+        const int max_blocks = g.ngroups < 512 ? g.ngroups : 512;
+        g.slab_bytes_p = (size_t)max_blocks * 64 * g.block_waves_p * 64 * sizeof(float);
+        const size_t pose_p = (size_t)max_blocks * 64 * 4 * sizeof(float);
+        const size_t pose_r = (size_t)g.pre_blocks * 64 * 4 * sizeof(float);
+        g.pose_bytes = (((pose_p > pose_r ? pose_p : pose_r)) + 15) & ~(size_t)15;
     }
-    g.at_bytes = (size_t)g.rbt * g.sbt * 64 * sizeof(float4);
-    g.pose_bytes = (((size_t)g.pre_blocks * 64 * 4 * sizeof(float)) + 15) & ~(size_t)15;
+    g.at_bytes = (size_t)g.ngroups * 3 * g.sbt * 64 * sizeof(float4);
     g.slab_bytes = (size_t)g.gemm_blocks * 64 * bw_waves(ns, ne) * 64 * sizeof(float);
     return g;
 }
@@ -522,7 +668,7 @@ int fr_launch_decode_backward_pack(const float* pc_shape, const float* pc_exp, i
     if (N <= 0 || ns + ne <= 0) return FR_OK;
     BwdGeom g = bwd_geom(N, ns, ne);
     hipLaunchKernelGGL(bwd_pack_kernel, dim3(2048), dim3(256), 0, stream, pc_shape, pc_exp, N, ns, ne, g.sbs, g.sbt,
-                       (long long)g.rbt, reinterpret_cast<float4*>(packed_t));
+                       (long long)g.ngroups, reinterpret_cast<float4*>(packed_t));
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
@@ -547,27 +693,33 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
     a.pose_part = reinterpret_cast<float*>(ws + g.dv_bytes);
     a.slab = reinterpret_cast<float*>(ws + g.dv_bytes + g.pose_bytes);
     a.B = B; a.N = N; a.ns = ns; a.ne = ne; a.im_size = im_size;
-    a.pre_blocks = g.pre_blocks; a.gemm_blocks = packed ? g.gemm_blocks_p : g.gemm_blocks; a.rows_per_block = g.rows_per_block;
+    a.pre_blocks = packed ? g.gemm_blocks_p : g.pre_blocks;   // (packed path: the fused kernel's workgroups write the pose partials)
+    a.gemm_blocks = packed ? g.gemm_blocks_p : g.gemm_blocks; a.rows_per_block = g.rows_per_block;
     a.At = reinterpret_cast<const float4*>(packed_t);
-    a.sbt = g.sbt; a.sbs = g.sbs; a.rbt = g.rbt; a.rb_per_block = g.rb_per_block;
+    a.sbt = g.sbt; a.sbs = g.sbs;
+    a.rbt = packed ? g.ngroups : g.rbt;
+    a.rb_per_block = packed ? g.groups_per_block : g.rb_per_block;
     a.exp_slot0 = packed ? 16 * g.sbs : bw_ns4(ns);
+    a.nslots = packed ? 64 * g.block_waves_p : 64 * bw_waves(ns, ne);
     for (int b0 = 0; b0 < B; b0 += 64) {
         a.b0 = b0;
         a.nbatch = min(B - b0, 64);
-        hipLaunchKernelGGL(bwd_prepass_kernel, dim3(g.pre_blocks), dim3(256), 0, stream, a);
         const int nbt = (a.nbatch + 15) / 16;
-        if (waves > 0 && packed) {
-            const dim3 gb(waves * 64);
-            if (nbt == 1) hipLaunchKernelGGL(bwd_gemm_ring_kernel<1>, dim3(a.gemm_blocks), gb, 0, stream, a);
-            else if (nbt == 2) hipLaunchKernelGGL(bwd_gemm_ring_kernel<2>, dim3(a.gemm_blocks), gb, 0, stream, a);
-            else if (nbt == 3) hipLaunchKernelGGL(bwd_gemm_ring_kernel<3>, dim3(a.gemm_blocks), gb, 0, stream, a);
-            else hipLaunchKernelGGL(bwd_gemm_ring_kernel<4>, dim3(a.gemm_blocks), gb, 0, stream, a);
-        } else if (waves > 0) {
-            const dim3 gb(waves * 64);
-            if (nbt == 1) hipLaunchKernelGGL(bwd_gemm_kernel<1>, dim3(g.gemm_blocks), gb, 0, stream, a);
-            else if (nbt == 2) hipLaunchKernelGGL(bwd_gemm_kernel<2>, dim3(g.gemm_blocks), gb, 0, stream, a);
-            else if (nbt == 3) hipLaunchKernelGGL(bwd_gemm_kernel<3>, dim3(g.gemm_blocks), gb, 0, stream, a);
-            else hipLaunchKernelGGL(bwd_gemm_kernel<4>, dim3(g.gemm_blocks), gb, 0, stream, a);
+        if (packed) {   // ONE launch: gradient tile -> dv rows in LDS -> MFMA reduction + the pose partial sums
+            const dim3 gb(g.block_waves_p * 64);
+            if (nbt == 1) hipLaunchKernelGGL(bwd_fused_kernel<1>, dim3(a.gemm_blocks), gb, 0, stream, a);
+            else if (nbt == 2) hipLaunchKernelGGL(bwd_fused_kernel<2>, dim3(a.gemm_blocks), gb, 0, stream, a);
+            else if (nbt == 3) hipLaunchKernelGGL(bwd_fused_kernel<3>, dim3(a.gemm_blocks), gb, 0, stream, a);
+            else hipLaunchKernelGGL(bwd_fused_kernel<4>, dim3(a.gemm_blocks), gb, 0, stream, a);
+        } else {
+            hipLaunchKernelGGL(bwd_prepass_kernel, dim3(g.pre_blocks), dim3(256), 0, stream, a);
+            if (waves > 0) {
+                const dim3 gb(waves * 64);
+                if (nbt == 1) hipLaunchKernelGGL(bwd_gemm_kernel<1>, dim3(g.gemm_blocks), gb, 0, stream, a);
+                else if (nbt == 2) hipLaunchKernelGGL(bwd_gemm_kernel<2>, dim3(g.gemm_blocks), gb, 0, stream, a);
+                else if (nbt == 3) hipLaunchKernelGGL(bwd_gemm_kernel<3>, dim3(g.gemm_blocks), gb, 0, stream, a);
+                else hipLaunchKernelGGL(bwd_gemm_kernel<4>, dim3(g.gemm_blocks), gb, 0, stream, a);
+            }
         }
         hipLaunchKernelGGL(bwd_reduce_kernel, dim3(4 + 64 * waves), dim3(RED_WAVES * 64), 0, stream, a);
     }

@@ -223,14 +223,18 @@ int fr_decode_3dmm_backward(const float* grad_vertex_proj, const float* params, 
                             int n_shape, int n_exp, float im_size, float* grad_params, void* workspace, size_t ws_bytes,
                             void* hip_stream);
 
-/* The same gradient with the basis in a K-major packed image (round 3).  fr_decode_3dmm_backward above reads pc_shape /
- * pc_exp in their reference layouts (no extra memory; 16-byte pieces at a 796-byte row stride: 70 us at 64 faces against a
- * 33 us matrix-pipe floor); a caller that takes gradients every step packs the basis ONCE into MFMA A-fragment order for
- * the reduction over the vertices -- fr_decode_backward_basis_bytes(N, n_shape, n_exp) bytes (the size of the forward image),
- * 16-byte aligned -- and calls the packed entry point, whose operand fetches are coalesced 1 KiB fragments through a
- * counted-wait register ring.  Same workspace (fr_decode_backward_workspace_bytes), same definition of every output,
- * deterministic; the two entry points sum their partial results in different (each fixed) orders, so they agree to
- * rounding, not bit for bit. */
+/* The same gradient from a packed basis image, in ONE fused kernel + the fixed-order reduction (round 4).
+ * fr_decode_3dmm_backward above reads pc_shape / pc_exp in their reference layouts (no extra memory) and runs three
+ * launches: a prepass that writes the 41 MB of dv rows, the reduction over the vertices, the slab sum (70 us of GEMM at 64
+ * faces against a 33 us matrix-pipe floor).  A caller that takes gradients every step packs the basis ONCE --
+ * fr_decode_backward_basis_bytes(N, n_shape, n_exp) bytes (the size of the forward image), 16-byte aligned: MFMA A-fragment
+ * order, [vertex group of 16][x / y / z rows][16-coefficient block][lane] float4 -- and calls the packed entry point: one
+ * workgroup per CU turns a 16-vertex tile of the incoming gradient into the three dv row blocks in LDS (and the d t3d / d f
+ * partial sums in registers) and multiplies them against the group's basis fragments (counted-wait register ring); dv never
+ * reaches global memory.  rocprofv3 at 64 faces: 27.6 + 59.4 + 16.7 us (round 3) -> 70.1 + 6.9 us.  Same workspace
+ * (fr_decode_backward_workspace_bytes), same definition of every output, deterministic (bit-reproducible for a given
+ * FR_BWD_CHUNKS); the two entry points sum their partial results in different (each fixed) orders, so they agree to rounding,
+ * not bit for bit. */
 size_t fr_decode_backward_basis_bytes(int N, int n_shape, int n_exp);
 int fr_decode_backward_pack_basis(const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp, void* packed_t,
                                   size_t packed_bytes, void* hip_stream);
