@@ -34,12 +34,13 @@ def kernel_stats(name, out):
                                  for r in hot}}
 
 
-for j in ("bench", "bench_k20", "bench_graph", "bench_q30"):
+for j in ("bench", "bench_k20", "bench_pipelined", "bench_graph", "bench_q30"):
     f = os.path.join(src, j + ".json")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.json" % (tag, j)))
 kernel_stats("prof_bench", "%s_kernel_stats.csv" % tag)
 kernel_stats("prof_bwd", "%s_decode_bwd_kernel_stats.csv" % tag)
+kernel_stats("prof_pipelined", "%s_pipelined_kernel_stats.csv" % tag)
 # the bench line printed by the SAME process the kernel stats come from (profiled: lower clocks, per-launch overhead)
 f = os.path.join(src, "prof_bench.log")
 if os.path.exists(f):
@@ -65,19 +66,44 @@ if os.path.exists(f):
     dec = next(v for k, v in pmc.items() if "decode_ring_kernel" in k)
     emit = next(v for k, v in pmc.items() if "raster_emit_kernel" in k)
     res = next(v for k, v in pmc.items() if "resolve_write_kernel" in k)
+    # rocprofv3 kernel averages of the same command (kernel_stats.csv of the prof_bench leg)
+    avg = {}
+    f2 = first("prof_bench/**/*kernel_stats.csv")
+    if f2:
+        for r in csv.DictReader(open(f2)):
+            for key, pat in (("decode", "decode_ring_kernel"), ("raster_emit", "raster_emit_kernel"), ("resolve_write", "resolve_write_kernel")):
+                if pat in r["Name"]:
+                    avg[key] = float(r["AverageNs"]) / 1e6
+    cal = None
+    f3 = os.path.join(src, "pmc_calibration.json")
+    if os.path.exists(f3):
+        cal = json.load(open(f3))
+        json.dump(cal, open(os.path.join(P, "%s_pmc_calibration.json" % tag), "w"), indent=1)
+    # ONE stated correction, calibrated on kernels of known traffic in each kernel's access shape (tools/pmc_calib.hip):
+    # FETCH_SIZE reads 0.500 of the bytes of 16-byte-per-lane streaming reads (the decode's fragments: doubled) and the bytes
+    # at face value for dword gathers and scattered 16-byte loads (emit, resolve: raw); WRITE_SIZE is exact for every store
+    # shape tried.  KiB * 1024, per launch.
+    def traffic(v, fetch_factor):
+        return (fetch_factor * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
     json.dump({
         "source": "rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- "
-                  "python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0, MI355X, %s kernels (profiles/%s_pmc.json); "
-                  "per launch, KiB * 1024.  decode streams 16 B/lane, so its FETCH_SIZE is doubled (MI355X_MICROARCH.md, "
-                  "HBM: gfx950 tallies 128-B requests at 64 B); the render kernels' dword gathers are uncalibrated and "
-                  "are reported raw." % (tag, tag),
-        "decode_bytes_per_launch": dec["hbm_bytes_fetch_x2"],
-        "render_bytes_per_launch": emit["hbm_bytes_raw"] + res["hbm_bytes_raw"],
-        "render_split": {"raster_emit_kernel": emit["hbm_bytes_raw"], "resolve_write_kernel": res["hbm_bytes_raw"]},
+                  "python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0, MI355X, "
+                  "%s kernels (profiles/%s_pmc.json); per launch" % (tag, tag),
+        "correction": "FETCH_SIZE x2 for the decode (16 B/lane streams are tallied at half), x1 for emit / resolve (gathers are "
+                      "tallied in full); WRITE_SIZE exact -- calibrated in profiles/%s_pmc_calibration.json" % tag,
+        "calibration": None if cal is None else {k: {"fetch_over_known": cal[k]["fetch_over_known"], "write_over_known": cal[k]["write_over_known"]}
+                                                 for k in ("calib_read16", "calib_gather4", "calib_write16", "calib_write4_12")},
         "batch": 64,
-        "kernels": ["decode_ring_kernel<13,2,8,2,16,64,4,true,NoProbe,true>", "raster_emit_kernel<NoEmitProbe>", "resolve_write_kernel<256>"],
+        "kernels": {
+            "decode": {"traffic_bytes_per_launch": traffic(dec, 2.0), "fetch_KiB": dec["FETCH_SIZE"], "write_KiB": dec["WRITE_SIZE"],
+                       "rocprofv3_avg_ms": avg.get("decode")},
+            "raster_emit": {"traffic_bytes_per_launch": traffic(emit, 1.0), "fetch_KiB": emit["FETCH_SIZE"], "write_KiB": emit["WRITE_SIZE"],
+                            "rocprofv3_avg_ms": avg.get("raster_emit")},
+            "resolve_write": {"traffic_bytes_per_launch": traffic(res, 1.0), "fetch_KiB": res["FETCH_SIZE"], "write_KiB": res["WRITE_SIZE"],
+                              "rocprofv3_avg_ms": avg.get("resolve_write")},
+        },
     }, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
-for extra in ("kernel_timing.log", "decode_breakdown.json", "decode_ab.json", "emit_phase_account.json", "bwd_probe.log"):
+for extra in ("kernel_timing.log", "decode_breakdown.json", "emit_phase_account.json", "emit_ablate.json", "bwd_probe.log", "legs.log"):
     f = os.path.join(src, extra)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s" % (tag, extra)))
