@@ -110,6 +110,7 @@ enum Opt {
     OPT_FUSED_ORDER,    // FR_FUSED_ORDER    resolve blocks of the fused launch: 0 = spread evenly (default), 1 = first, 2 = last
     OPT_FUSED_ALONE,    // FR_FUSED_ALONE    1 = a lone emit / resolve phase of the pipelined entry also runs through the fused kernel (probe)
     OPT_BWD_CHUNKS,     // FR_BWD_CHUNKS     row chunks (workgroups, partial slabs) of the packed decode-backward GEMM: 256 (default: one workgroup per CU), 1 .. 512
+    OPT_BWD_CB,         // FR_BWD_CB         16-coefficient blocks per wave of the fused decode backward: 0 = by batch (default) | 2 | 4
     OPT_COUNT
 };
 int opt(Opt o);

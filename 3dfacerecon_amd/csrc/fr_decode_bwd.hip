@@ -323,8 +323,12 @@ __global__ __launch_bounds__(256) void bwd_pack_kernel(const float* __restrict__
 // blocks (twelve 1 KiB fragments per wave, two groups in flight) against them.  dv never exists in global memory: g and
 // vertex_proj are read once, the 41 MB write + re-read and the prepass launch are gone.
 // Summation order: per output, groups ascending, x / y / z row block, k-step -- fixed by the chunking (FR_BWD_CHUNKS) alone.
-template <int NB>
-__global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_fused_kernel(BwdArgs a) {
+// CB: 16-coefficient blocks per wave.  CB = 2 (eight waves for the model's 15 blocks: two per SIMD, one multiplying while the
+// other waits for its fragments) or 4 (four waves, one per SIMD; also what bases of more than 16 blocks take).
+// Either way the packed path covers bases of at most 16 blocks (256 coefficients: the model has 228); larger ones take the
+// reference-layout entry point (fr_decode_backward_basis_bytes answers 0 for them).
+template <int NB, int CB>
+__global__ __launch_bounds__(CB == 2 ? 512 : 256) void bwd_fused_kernel(BwdArgs a) {
     __shared__ float Mt[64][13];                                            // f*R (9), t (3), 1/f or 0
     __shared__ __attribute__((aligned(16))) float4 dvL[2][3][4][64];        // [buffer][coordinate][k-step][lane] (mb in .xyzw)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -359,25 +363,27 @@ __global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_fused_kernel(BwdArgs a) 
     const int bc = min(sb_, a.nbatch - 1);   // (dead columns load a live column's tile and discard it)
     const float* gx = a.g + (size_t)(a.b0 + bc) * 3 * N + 4 * q;
     const float* vx = a.vproj + (size_t)(a.b0 + bc) * 3 * N + 4 * q;
-    // MFMA role: this wave's four 16-coefficient blocks
+    // MFMA role: this wave's CB 16-coefficient blocks
     const int kq = lane >> 4, jn = lane & 15;
     const int sbt = a.sbt;
-    const int sb0 = 4 * wave;
-    const int nsb = max(0, min(4, sbt - sb0));           // live ones (wave-uniform; 0: a staging-only wave)
+    const int sb0 = CB * wave;
+    const int nsb = max(0, min(CB, sbt - sb0));          // live ones (wave-uniform; 0: a staging-only wave)
+    const bool stage_wave = wave < 4;                    // (wave-uniform: the 256 staging threads are waves 0..3)
     const long long g_begin = (long long)blockIdx.x * a.rb_per_block;              // (rb_per_block = vertex groups per workgroup)
     const long long g_end = min((long long)a.rbt, g_begin + a.rb_per_block);       // (rbt = vertex groups in all)
     const int n = (int)(g_end - g_begin);
-    f32x4 acc[4][NB];
+    f32x4 acc[CB][NB];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < CB; i++)
 #pragma unroll
         for (int mb = 0; mb < NB; mb++) acc[i][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 ra[2][3][4];     // basis fragments of two groups in flight: [slot][coordinate][coefficient block]
+    f32x4 ra[2][3][CB];    // basis fragments of two groups in flight: [slot][coordinate][coefficient block]
     f32x4 tg[3], tv[3];    // the tile: g and vertex_proj, x / y / z rows, this thread's four vertices
     float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;   // pose partial sums of this thread's column: d t3d (3), sum (q - t) . dq
     // requests (a group past the end re-requests the last one and is never consumed; a dead coefficient block re-requests the
     // image's last block: every wave issues the same number of loads in the same order, which is what the counted waits count)
     auto req_tile = [&](long long grp) {
+        if (!stage_wave) return;   // (a wave without staging threads requests no tile: its counted waits count accordingly)
         const long long gc = min(grp, (long long)a.rbt - 1);
         // (the LAST group's vertices may end before its sixteen: its loads are clamped to stay inside the rows; the values
         // of the missing vertices are zeroed by the mask below)
@@ -394,10 +400,15 @@ __global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_fused_kernel(BwdArgs a) 
         const long long gc = min(grp, (long long)a.rbt - 1);
         const float4* ab = a.At + ((size_t)(gc * 3 + c) * sbt) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < CB; i++) {
             const float4* p = ab + (size_t)min(sb0 + i, sbt - 1) * 64;
             FRB_LD(ra[d][c][i], p);
         }
+    };
+    // counted waits: the tile is followed by the 3 CB fragments of its group; a coordinate's CB fragments by 5 CB fragments
+    // (+ 12 tile loads in a staging wave)
+    auto wait_tile = [&]() {
+        if (stage_wave) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(tg[0]), "+v"(tg[1]), "+v"(tg[2]), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]) : "n"(3 * CB));
     };
     // tile -> dv rows of group grp into LDS buffer `buf` + the pose partial sums (tile registers must have arrived)
     auto stage = [&](long long grp, int buf) {
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_fused_kernel(BwdArgs a) 
         req_tile(g_begin);
 #pragma unroll
         for (int c = 0; c < 3; c++) req_basis(0, c, g_begin);
-        asm volatile("s_waitcnt vmcnt(12)" : "+v"(tg[0]), "+v"(tg[1]), "+v"(tg[2]), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]));
+        wait_tile();
         stage(g_begin, 0);
         req_tile(g_begin + 1);
 #pragma unroll
@@ -470,22 +481,29 @@ __global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_fused_kernel(BwdArgs a) 
                 const int i = i0 + d;
                 const long long grp = g_begin + i;
                 // tile of group i + 1 (behind it: the twelve fragments of group i + 1)
-                asm volatile("s_waitcnt vmcnt(12)" : "+v"(tg[0]), "+v"(tg[1]), "+v"(tg[2]), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]));
+                wait_tile();
                 // every wave has finished reading buffer d ^ 1 (group i - 1); buffer d (group i, written last trip) is published
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (i + 1 < n) stage(grp + 1, d ^ 1);
                 req_tile(grp + 2);
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    // the four fragments of (group i, coordinate c): 32 younger loads are in flight behind them
-                    asm volatile("s_waitcnt vmcnt(32)" : "+v"(ra[d][c][0]), "+v"(ra[d][c][1]), "+v"(ra[d][c][2]), "+v"(ra[d][c][3]));
+                    // the CB fragments of (group i, coordinate c), the oldest loads in flight
+                    if constexpr (CB == 4) {
+                        if (stage_wave) asm volatile("s_waitcnt vmcnt(32)" : "+v"(ra[d][c][0]), "+v"(ra[d][c][1]), "+v"(ra[d][c][2]), "+v"(ra[d][c][3]));
+                        else asm volatile("s_waitcnt vmcnt(20)" : "+v"(ra[d][c][0]), "+v"(ra[d][c][1]), "+v"(ra[d][c][2]), "+v"(ra[d][c][3]));
+                    } else {
+                        static_assert(CB == 2 || CB == 4, "coefficient blocks per wave");
+                        if (stage_wave) asm volatile("s_waitcnt vmcnt(22)" : "+v"(ra[d][c][0]), "+v"(ra[d][c][1]));
+                        else asm volatile("s_waitcnt vmcnt(10)" : "+v"(ra[d][c][0]), "+v"(ra[d][c][1]));
+                    }
                     if (nsb > 0 && i < n) {
 #pragma unroll
                         for (int j = 0; j < 4; j++) {          // k-step: rows 4 j .. 4 j + 3 of the row block, ascending
                             const float4 bv = dvL[d][c][j][lane];
                             const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                            for (int ii = 0; ii < 4; ii++)
+                            for (int ii = 0; ii < CB; ii++)
                                 if (ii < nsb) {
 #pragma unroll
                                     for (int mb = 0; mb < NB; mb++)
@@ -501,7 +519,8 @@ __global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_fused_kernel(BwdArgs a) 
         for (int dd = 0; dd < 2; dd++)
 #pragma unroll
             for (int c = 0; c < 3; c++)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[dd][c][0]), "+v"(ra[dd][c][1]), "+v"(ra[dd][c][2]), "+v"(ra[dd][c][3]));
+#pragma unroll
+                for (int ii = 0; ii < CB; ii++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[dd][c][ii]));
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(tg[0]), "+v"(tg[1]), "+v"(tg[2]), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]));
     }
     // pose partial sums: the four vertex quads of a column are the four lanes of a DPP quad -- (q0 + q1) + (q2 + q3), fixed
@@ -516,16 +535,16 @@ __global__ __launch_bounds__(BW_MAXWAVES * 64) void bwd_fused_kernel(BwdArgs a) 
             pp[0] = ps0; pp[1] = ps1; pp[2] = ps2; pp[3] = ps3 * m[12];
         }
     }
-    // D tile of coefficient block i: row m = 4 * (lane >> 4) + reg is slot 64 wave + 16 i + m, column (batch in block) = lane & 15
+    // D tile of coefficient block i: row m = 4 * (lane >> 4) + reg is slot 16 (CB wave + i) + m, column (batch in block) = lane & 15
     float* slab = a.slab + (size_t)blockIdx.x * a.nslots * 64;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < CB; i++)
         if (i < nsb) {
 #pragma unroll
             for (int mb = 0; mb < NB; mb++)
 #pragma unroll
                 for (int rg = 0; rg < 4; rg++) {
-                    const int slot = 64 * wave + 16 * i + 4 * kq + rg;
+                    const int slot = 16 * (CB * wave + i) + 4 * kq + rg;
                     slab[(size_t)slot * 64 + 16 * mb + jn] = acc[i][mb][rg];
                 }
         }
@@ -607,6 +626,7 @@ struct BwdGeom {
     // packed-image variant
     int sbs, sbt, rbt, rb_per_block, gemm_blocks_p, waves_p;
     int ngroups, groups_per_block, block_waves_p;   // packed path: vertex groups of 16, per workgroup; waves per workgroup
+    int cb_p;                                       // packed path: 16-coefficient blocks per wave (2 or 4)
     size_t slab_bytes_p, at_bytes;
 };
 static BwdGeom bwd_geom(int N, int ns = 199, int ne = 29) {
@@ -636,7 +656,11 @@ static BwdGeom bwd_geom(int N, int ns = 199, int ne = 29) {
     g.groups_per_block = (g.ngroups + chunks - 1) / chunks;
     if (g.groups_per_block < 1) g.groups_per_block = 1;
     g.gemm_blocks_p = g.ngroups > 0 ? (g.ngroups + g.groups_per_block - 1) / g.groups_per_block : 0;
-    g.block_waves_p = g.waves_p < 4 ? 4 : g.waves_p;   // (the 256 staging threads of bwd_fused_kernel)
+    // FR_BWD_CB: 16-coefficient blocks per wave -- 2 (eight waves, two per SIMD), 4 (four waves), 0 = by batch (below).
+    // Same-box runs through the autograd surface: 64 faces 77 us (2) vs 80 (4); 32 faces 73 (2) vs 67 (4).
+    g.cb_p = opt(OPT_BWD_CB) == 4 ? 4 : 2;
+    g.block_waves_p = (g.sbt + g.cb_p - 1) / g.cb_p;
+    if (g.block_waves_p < 4) g.block_waves_p = 4;      // (the 256 staging threads of bwd_fused_kernel)
     {
         const int max_blocks = g.ngroups < 512 ? g.ngroups : 512;
         g.slab_bytes_p = (size_t)max_blocks * 64 * g.block_waves_p * 64 * sizeof(float);
@@ -657,8 +681,11 @@ size_t fr_decode_backward_workspace_impl(int N, int ns, int ne) {
     return g.dv_bytes + g.pose_bytes + (g.slab_bytes > g.slab_bytes_p ? g.slab_bytes : g.slab_bytes_p);
 }
 
+// the packed path serves bases of at most 16 coefficient blocks (see bwd_fused_kernel)
+static bool bwd_packed_supported(int ns, int ne) { return ns + ne > 0 && (ns + 15) / 16 + (ne + 15) / 16 <= 16; }
+
 size_t fr_decode_backward_basis_bytes_impl(int N, int ns, int ne) {
-    if (N <= 0 || ns + ne <= 0) return 0;
+    if (N <= 0 || !bwd_packed_supported(ns, ne)) return 0;
     return fr::bwd_geom(N, ns, ne).at_bytes;
 }
 
@@ -666,6 +693,7 @@ int fr_launch_decode_backward_pack(const float* pc_shape, const float* pc_exp, i
                                    hipStream_t stream) {
     using namespace fr;
     if (N <= 0 || ns + ne <= 0) return FR_OK;
+    if (!bwd_packed_supported(ns, ne)) return FR_ERR_UNSUPPORTED;
     BwdGeom g = bwd_geom(N, ns, ne);
     hipLaunchKernelGGL(bwd_pack_kernel, dim3(2048), dim3(256), 0, stream, pc_shape, pc_exp, N, ns, ne, g.sbs, g.sbt,
                        (long long)g.ngroups, reinterpret_cast<float4*>(packed_t));
@@ -683,6 +711,7 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
                                                                                                              : FR_ERR_LAUNCH;
     BwdGeom g = bwd_geom(N, ns, ne);
     const bool packed = packed_t != nullptr;
+    if (packed && !bwd_packed_supported(ns, ne)) return FR_ERR_UNSUPPORTED;
     const int waves = packed ? g.waves_p : bw_waves(ns, ne);
     if (waves > BW_MAXWAVES) return FR_ERR_UNSUPPORTED;  // > 512 coefficient slots
     BwdArgs a;
@@ -700,17 +729,31 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
     a.rbt = packed ? g.ngroups : g.rbt;
     a.rb_per_block = packed ? g.groups_per_block : g.rb_per_block;
     a.exp_slot0 = packed ? 16 * g.sbs : bw_ns4(ns);
-    a.nslots = packed ? 64 * g.block_waves_p : 64 * bw_waves(ns, ne);
+    a.nslots = packed ? 16 * g.cb_p * g.block_waves_p : 64 * bw_waves(ns, ne);
     for (int b0 = 0; b0 < B; b0 += 64) {
         a.b0 = b0;
         a.nbatch = min(B - b0, 64);
         const int nbt = (a.nbatch + 15) / 16;
         if (packed) {   // ONE launch: gradient tile -> dv rows in LDS -> MFMA reduction + the pose partial sums
+            if (opt(OPT_BWD_CB) == 0) {   // by batch: four blocks per wave up to 32 live columns, two beyond
+                const int cb = nbt <= 2 ? 4 : 2;
+                if (cb != g.cb_p) {
+                    g.cb_p = cb;
+                    g.block_waves_p = (g.sbt + cb - 1) / cb < 4 ? 4 : (g.sbt + cb - 1) / cb;
+                    a.nslots = 16 * cb * g.block_waves_p;
+                }
+            }
             const dim3 gb(g.block_waves_p * 64);
-            if (nbt == 1) hipLaunchKernelGGL(bwd_fused_kernel<1>, dim3(a.gemm_blocks), gb, 0, stream, a);
-            else if (nbt == 2) hipLaunchKernelGGL(bwd_fused_kernel<2>, dim3(a.gemm_blocks), gb, 0, stream, a);
-            else if (nbt == 3) hipLaunchKernelGGL(bwd_fused_kernel<3>, dim3(a.gemm_blocks), gb, 0, stream, a);
-            else hipLaunchKernelGGL(bwd_fused_kernel<4>, dim3(a.gemm_blocks), gb, 0, stream, a);
+#define FR_BWD_LAUNCH(NBV)                                                                                            \
+    {                                                                                                                 \
+        if (g.cb_p == 2) hipLaunchKernelGGL((bwd_fused_kernel<NBV, 2>), dim3(a.gemm_blocks), gb, 0, stream, a);       \
+        else hipLaunchKernelGGL((bwd_fused_kernel<NBV, 4>), dim3(a.gemm_blocks), gb, 0, stream, a);                   \
+    }
+            if (nbt == 1) FR_BWD_LAUNCH(1)
+            else if (nbt == 2) FR_BWD_LAUNCH(2)
+            else if (nbt == 3) FR_BWD_LAUNCH(3)
+            else FR_BWD_LAUNCH(4)
+#undef FR_BWD_LAUNCH
         } else {
             hipLaunchKernelGGL(bwd_prepass_kernel, dim3(g.pre_blocks), dim3(256), 0, stream, a);
             if (waves > 0) {

@@ -80,6 +80,8 @@ class PackedBasis:
             h = _host()
             L = h.lib()
             nbytes = L.fr_decode_backward_basis_bytes(self.nvert, self.ndim_shape, self.ndim_exp)
+            if nbytes == 0:   # a basis the packed kernel does not serve (more than 256 coefficients): reference-layout entry point
+                return None
             buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=self.device)
             with torch.cuda.device(self.device):
                 rc = L.fr_decode_backward_pack_basis(h.ptr(self.pc_shape), h.ptr(self.pc_exp), self.nvert, self.ndim_shape,
@@ -158,12 +160,20 @@ class _Decode3DMM(torch.autograd.Function):
         with torch.cuda.device(params.device):
             nws = L.fr_decode_backward_workspace_bytes(B, net.nvert, net.ndim_shape, net.ndim_exp)
             ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=params.device)
-            # (the reduction over the vertices streams the K-major packed image: built once per basis, at the first backward)
-            rc = L.fr_decode_3dmm_backward_packed(h.ptr(g), h.ptr(params), h.ptr(out), h.ptr(ctx.basis.image_t()),
-                                                  h.ptr(R) if ctx.has_R else None, B, net.nvert, net.ndim_shape,
-                                                  net.ndim_exp, ctx.im_size, h.ptr(gp), h.ptr(ws), nws,
-                                                  h.stream_ptr(params.device))
-        h.check(rc, "fr_decode_3dmm_backward_packed")
+            # (the fused kernel streams the packed image: built once per basis, at the first backward; bases beyond 256
+            # coefficients -- not the model's -- take the reference-layout entry point)
+            img = ctx.basis.image_t()
+            if img is not None:
+                rc = L.fr_decode_3dmm_backward_packed(h.ptr(g), h.ptr(params), h.ptr(out), h.ptr(img),
+                                                      h.ptr(R) if ctx.has_R else None, B, net.nvert, net.ndim_shape,
+                                                      net.ndim_exp, ctx.im_size, h.ptr(gp), h.ptr(ws), nws,
+                                                      h.stream_ptr(params.device))
+            else:
+                rc = L.fr_decode_3dmm_backward(h.ptr(g), h.ptr(params), h.ptr(out), h.ptr(ctx.basis.pc_shape),
+                                               h.ptr(ctx.basis.pc_exp), h.ptr(R) if ctx.has_R else None, B, net.nvert,
+                                               net.ndim_shape, net.ndim_exp, ctx.im_size, h.ptr(gp), h.ptr(ws), nws,
+                                               h.stream_ptr(params.device))
+        h.check(rc, "fr_decode_3dmm_backward")
         return gp, None, None, None, None
 
 

@@ -50,6 +50,7 @@ const char* fr_strerror(int code);
  *   FR_FUSED_ALONE (0 | 1 = probe: a lone emit / resolve phase of the pipelined entry also runs through the fused kernel)
  *   FR_BWD_CHUNKS (row chunks of the packed decode-backward GEMM: 256 = default | 1 .. 512; changes the association of the
  *   partial sums, i.e. the gradient's last bits -- every other knob leaves every result bit unchanged)
+ *   FR_BWD_CB (16-coefficient blocks per wave of the fused decode backward: 0 = by batch | 2 | 4)
  * None of them changes a result bit (tests/test_render_gpu.py, tests/test_decode_gpu.py hold every setting to the oracle).
  * Returns FR_OK or FR_ERR_INVALID_ARG (unknown name). */
 int fr_set_option(const char* name, int value);

@@ -102,11 +102,11 @@ def test_zero_focal_column(oracle, synth):
 
 
 def test_packed_and_reference_layout_entry_points(oracle, synth):
-    """fr_decode_3dmm_backward (basis in its reference layout, no extra memory) and fr_decode_3dmm_backward_packed (K-major
-    image, counted-wait ring: the one the autograd node uses) are the same gradient with differently ordered -- each fixed --
-    partial sums: both within tolerance of the float64 gradient, each bit-reproducible, at a ragged shape (N = 187: the last
-    16-row block of the packed image and of dv is padding; 217 coefficients: 14 + 1 blocks, the last wave has 3 live) and at
-    the model's 199 + 29 with 70 faces (two passes)."""
+    """fr_decode_3dmm_backward (basis in its reference layout, no extra memory: prepass + GEMM + reduce) and
+    fr_decode_3dmm_backward_packed (packed image, ONE fused kernel + reduce: the one the autograd node uses) are the same
+    gradient with differently ordered -- each fixed -- partial sums: both within tolerance of the float64 gradient, each
+    bit-reproducible, at a ragged shape (N = 187: the last vertex group is 11 vertices; 217 coefficients: 13 + 2 blocks, the
+    last wave has one live), at the model's 199 + 29 with 70 faces (two passes) and at a one-block basis (staging-only waves)."""
     import ctypes
     from conftest import pkg
     h = pkg("_lib")
