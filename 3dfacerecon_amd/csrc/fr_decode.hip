@@ -297,7 +297,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_kernel(DecodeArgs a) {
 // Development hooks: the product instantiates the kernel with NoProbe only (every hook is an empty inline or a
 // compile-time-false branch); tools/decode_probe.hip supplies policies with ablation bits
 // (1 = no MFMA, 2 = requests hit 256 tiles, 4 = no prologue, 8 = no A requests, 16 = no LDS B reads, 32 = (almost) no
-// stores) and in-kernel s_memtime stamps.
+// stores, 64 = the stores issued as whole 128-byte lines: timing only) and in-kernel s_memtime stamps.
 struct NoProbe {
     static constexpr int bits = 0;
     __device__ __forceinline__ void begin() {}
@@ -479,7 +479,8 @@ void decode_ring_kernel(DecodeArgs a) {
         }
         pr.item_mfma_done();
         if ((PR::bits & 32) == 0 || c[0][0][0] + c[1][0][1] + c[2][NBW - 1][2] == 12345.678f) {
-            if constexpr (TR) decode_store_tr<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
+            if constexpr ((PR::bits & 64) != 0) decode_store_fullline_probe<NBW>(a, c[0], c[1], c[2], ct, hf, lane, nbatch, N);
+            else if constexpr (TR) decode_store_tr<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
             else decode_store<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
         }
         pr.item_end();

@@ -184,4 +184,24 @@ __device__ __forceinline__ void decode_store_tr(const DecodeArgs& a, const f32x4
     }
 }
 
+// PROBE ONLY (tools/decode_probe.hip, ablation bit 64; the product never instantiates it): the item's 6 KiB leave as 24
+// one-dword-per-lane stores that each write TWO WHOLE 128-byte lines -- the store stream a transposed v_mfma_f32_32x32x2_f32
+// item (lane = vertex of 32, registers = batches) would issue.  The two tiles of a pair take alternate (batch, coordinate)
+// rows, so every line of the output is written exactly once; the VALUES land in the wrong places: timing only.
+template <int NBW>
+__device__ __forceinline__ void decode_store_fullline_probe(const DecodeArgs& a, const f32x4 (&s0)[NBW], const f32x4 (&s1)[NBW],
+                                                            const f32x4 (&s2)[NBW], int tile, int hf, int lane, int nbatch, int N) {
+    const int par = tile & 1, half = lane >> 5;
+    const size_t v = (size_t)(tile & ~1) * TILE_V + (lane & 31);   // the tile pair's 32 vertices
+    if (v >= (size_t)N) return;
+#pragma unroll
+    for (int s = 0; s < 24; s++) {
+        const int row = 2 * (2 * s + half) + par;     // this tile's half of the item's 96 (batch, coordinate) rows
+        const int bb = 16 * hf * NBW + row / 3, cc = row - 3 * (row / 3);
+        if (bb >= nbatch) continue;
+        const float val = (cc == 0 ? s0 : cc == 1 ? s1 : s2)[(s >> 2) % NBW][s & 3];
+        a.out[((size_t)(a.b0 + bb) * 3 + cc) * a.pitch + v] = val;
+    }
+}
+
 }  // namespace fr

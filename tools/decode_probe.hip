@@ -297,6 +297,8 @@ int main(int argc, char** argv) {
     if (quick) {
         ROW("no_mfma(1)", AblateProbe<1>) ",");
         ROW("no_stores(32)", AblateProbe<32>) ",");
+        ROW("stores_as_whole_128B_lines_timing_only(64)", AblateProbe<64>) ",");
+        ROW("no_mfma_stores_as_whole_lines(65)", AblateProbe<65>) ",");
         ROW("full_again", AblateProbe<0>) "");
         printf(" },\n \"stamps\": [\n");
         stamped<true, 0>(c, true, "product configuration (nt basis), basis from HBM", dstamps, true);
