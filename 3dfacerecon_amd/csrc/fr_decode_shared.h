@@ -191,16 +191,20 @@ __device__ __forceinline__ void decode_store_tr(const DecodeArgs& a, const f32x4
 template <int NBW>
 __device__ __forceinline__ void decode_store_fullline_probe(const DecodeArgs& a, const f32x4 (&s0)[NBW], const f32x4 (&s1)[NBW],
                                                             const f32x4 (&s2)[NBW], int tile, int hf, int lane, int nbatch, int N) {
+    // rows of the output are indexed (batch * 3 + coordinate) linearly: the item's 96 rows are 96 consecutive row indices, the
+    // tile of parity `par` takes the row pairs p = 2 s + par, the half wave `half` row 2 p + half -- one pointer per lane, a
+    // constant stride per store, no index arithmetic beside the stores (a first version derived batch / coordinate per store
+    // and measured its own divisions: 129 us)
     const int par = tile & 1, half = lane >> 5;
     const size_t v = (size_t)(tile & ~1) * TILE_V + (lane & 31);   // the tile pair's 32 vertices
-    if (v >= (size_t)N) return;
+    if (v >= (size_t)N || nbatch < MAXB) return;                   // (the probe runs full 64-column passes only)
+    float* p = a.out + ((size_t)(a.b0 * 3 + 96 * hf) + 2 * par + half) * a.pitch + v;
+    const size_t stride = 4 * (size_t)a.pitch;
 #pragma unroll
     for (int s = 0; s < 24; s++) {
-        const int row = 2 * (2 * s + half) + par;     // this tile's half of the item's 96 (batch, coordinate) rows
-        const int bb = 16 * hf * NBW + row / 3, cc = row - 3 * (row / 3);
-        if (bb >= nbatch) continue;
+        const int cc = s % 3;
         const float val = (cc == 0 ? s0 : cc == 1 ? s1 : s2)[(s >> 2) % NBW][s & 3];
-        a.out[((size_t)(a.b0 + bb) * 3 + cc) * a.pitch + v] = val;
+        p[(size_t)s * stride] = val;
     }
 }
 
