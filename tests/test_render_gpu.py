@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, grid_from_rows, kat_inputs, pkg
-from gpu_util import assert_render_equal, render_gpu
+from gpu_util import assert_render_equal, ops, render_gpu
 
 pytestmark = pytest.mark.gpu
 KAT = json.load(open(os.path.join(GOLDEN, "kat_survey.json")))
@@ -459,3 +459,27 @@ def test_resolver_wave_local_front_overflow_and_fallback(oracle, nsegs, with_big
         with host.options(FR_RESOLVE_OPT=opt):
             got = render_gpu(ver, tri, tex, H, W)
         assert_render_equal(got, want, "FR_RESOLVE_OPT=%d, %d segments%s" % (opt, nsegs, ", big triangle" if with_big else ""))
+
+
+def test_render_depth_under_inference_mode(oracle):
+    """A forward-only serving set-up: tensors created under torch.inference_mode() have no version counter (reading it
+    raises).  The operator surface must render them -- the triangle table is then packed every call instead of being
+    cached against a version it cannot see -- and an in-place change of `tri` must show in the very next call."""
+    rs = np.random.RandomState(77)
+    B, nver, ntri, H, W = 2, 60, 90, 24, 20
+    ver = np.stack([rs.uniform(-2, W + 2, (B, nver)), rs.uniform(-2, H + 2, (B, nver)), rs.uniform(-5, 5, (B, nver))], 1).astype(np.float32)
+    tri = rs.randint(0, nver, (3, ntri)).astype(np.float32)
+    tex = rs.uniform(0, 1, (1, 3, nver)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    with torch.inference_mode():
+        v, t, x = (torch.as_tensor(a_, device=dev) for a_ in (ver, tri, tex))
+        assert t.is_inference()
+        img = torch.zeros((B, H, W, 3), device=dev)
+        for rnd in range(2):
+            got = tuple(o.cpu().numpy() for o in ops().render_depth(v, t, x, img))
+            assert_render_equal(got, oracle.render_depth(ver, tri, tex, H, W), "inference mode, call %d" % rnd)
+        tri2 = tri.copy()
+        tri2[:, ::2] = tri2[::-1, ::2]                       # another triangle list, written IN PLACE into the same tensor
+        t.copy_(torch.as_tensor(tri2, device=dev))
+        got = tuple(o.cpu().numpy() for o in ops().render_depth(v, t, x, img))
+        assert_render_equal(got, oracle.render_depth(ver, tri2, tex, H, W), "inference mode, tri rewritten in place")
