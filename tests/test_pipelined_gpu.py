@@ -2,6 +2,8 @@
 ONE launch.  Bars: the planes are bit-identical to the serial plan's on the same parameters (all 64 full-size faces) and to
 the CPU oracle on arbitrary scenes -- sub-pixel grids, random soup, oversized triangles (the resolver rasterises those from
 the PREVIOUS batch's vertices), integer ties, NaN / Inf / bad ids -- through both roles of the fused launch."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -22,7 +24,10 @@ def _second_batch(ver, seed):
     return v
 
 
-@pytest.mark.parametrize("seed", range(48))
+N_SCENES = max(48, int(os.environ.get("FR_FUZZ_CASES", "0")) * 3 // 10)   # FR_FUZZ_CASES widens this sweep too
+
+
+@pytest.mark.parametrize("seed", range(N_SCENES))
 def test_fused_launch_both_roles_vs_oracle(oracle, seed):
     ver, tri, tex, H, W = _scene(7000 + seed)
     ver_b = _second_batch(ver, seed)
