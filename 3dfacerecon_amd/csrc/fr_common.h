@@ -4,6 +4,7 @@
 // explicitly (__builtin_fmaf, MFMA).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <limits.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -80,14 +81,17 @@ __device__ __forceinline__ bool point_in_tri(const TriSetup& s, int x, int y) {
 }  // namespace fr
 
 // Raise a kernel's dynamic-LDS limit to the CU's full 160 KiB, once per (kernel, device): not a stream operation, so
-// it is kept out of the steady-state launch path (and out of hipGraph captures).
-inline hipError_t fr_allow_full_lds(const void* kernel, unsigned char* done /*[64], zero-initialised*/) {
+// it is kept out of the steady-state launch path (and out of hipGraph captures).  The per-device "done" flags are atomics:
+// the entry points may be called from several host threads (the header says so); two threads racing here both set the same
+// attribute to the same value and both store 1 -- idempotent, and now also free of a data race in the C++ sense.
+typedef std::atomic<unsigned char> fr_lds_flags_t;
+inline hipError_t fr_allow_full_lds(const void* kernel, fr_lds_flags_t* done /*[64], zero-initialised (static storage)*/) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = 1;
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
     return e;
 }
 

@@ -520,20 +520,20 @@ int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc
 }
 
 int fr_device_cu_count() {
-    static int cus[64];
+    static std::atomic<int> cus[64];   // (per-device cache; racing threads store the same value)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cus[dev] == 0) {
-        int n = 0;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
-    return cus[dev];
+    return n;
 }
 
 template <int NBW, int WAVES>
 static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int cus, size_t tiles, hipStream_t stream) {
-    static unsigned char lds_ok[64];
+    static fr_lds_flags_t lds_ok[64];
     if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_kernel<NBW, WAVES>), lds_ok) != hipSuccess)
         return FR_ERR_LAUNCH;
     const int slots = WAVES / a.halves;
@@ -545,7 +545,7 @@ static int launch_decode_nbw(const fr::DecodeArgs& a, size_t lds, int cus, size_
 template <int GS, int GE, int R, int NBW, int WAVES, int MB = 64, int WPE = WAVES / 4, bool NT = false, bool PRIO = false,
           bool TR = false>
 static int launch_decode_ring(const fr::DecodeArgs& a, size_t lds, int cus, size_t tiles, hipStream_t stream) {
-    static unsigned char lds_ok[64];
+    static fr_lds_flags_t lds_ok[64];
     if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_ring_kernel<GS, GE, R, NBW, WAVES, MB, WPE, NT, fr::NoProbe, PRIO, TR>),
                           lds_ok) != hipSuccess)
         return FR_ERR_LAUNCH;

@@ -554,7 +554,7 @@ bool fr_decode_q_supported(int n_shape, int n_exp) { return n_shape + n_exp <= 5
 
 template <int NBW>
 static int launch_q_generic(const fr::DecodeQArgs& a, size_t lds, int cus, hipStream_t stream) {
-    static unsigned char lds_ok[64];
+    static fr_lds_flags_t lds_ok[64];
     if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_q_kernel<NBW, 8>), lds_ok) != hipSuccess)
         return FR_ERR_LAUNCH;
     const int tiles = fr::tiles_of(a.d.N);
@@ -565,7 +565,7 @@ static int launch_q_generic(const fr::DecodeQArgs& a, size_t lds, int cus, hipSt
 
 template <int R, int NBW, int WAVES, bool NT>
 static int launch_q_ring(const fr::DecodeQArgs& a, int cus, hipStream_t stream) {
-    static unsigned char lds_ok[64];
+    static fr_lds_flags_t lds_ok[64];
     const void* k = reinterpret_cast<const void*>(&fr::decode_q_ring_kernel<R, NBW, WAVES, WAVES / 4, NT>);
     if (fr_allow_full_lds(k, lds_ok) != hipSuccess) return FR_ERR_LAUNCH;
     const size_t lds = fr::q_stage_bytes(fr::QR_S) + (size_t)WAVES * 256 + (size_t)WAVES * 2 * NBW * 1024;

@@ -1680,7 +1680,7 @@ size_t fr_render_workspace_bytes_impl(int B, int ntri, int H, int W) {
 
 template <int BLK, bool FUSED>
 static int launch_resolve(const fr::RenderArgs& a, long long nbins, size_t lds, hipStream_t stream) {
-    static unsigned char ok[64];
+    static fr_lds_flags_t ok[64];
     if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::resolve_write_kernel<BLK, FUSED>), ok) != hipSuccess)
         return FR_ERR_LAUNCH;
     hipLaunchKernelGGL((fr::resolve_write_kernel<BLK, FUSED>), dim3((unsigned)nbins), dim3(BLK),
@@ -1776,7 +1776,7 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     const long long nbins = (long long)B * g.strips;
     if (!binned) {
         if (!(phases & 2)) return FR_OK;  // the fallback is a single kernel: it counts as the resolve phase
-        static unsigned char lds_ok[64];
+        static fr_lds_flags_t lds_ok[64];
         if (fr_allow_full_lds(reinterpret_cast<const void*>(&render_strip_kernel<BLOCK>), lds_ok) != hipSuccess)
             return FR_ERR_LAUNCH;
         hipLaunchKernelGGL(render_strip_kernel<BLOCK>, dim3((unsigned)nbins), dim3(BLOCK), g.lds, stream, a);
@@ -1935,7 +1935,7 @@ int fr_launch_render_backward(const float* depth_grad, const float* tri, const f
     a.partial = packed ? partial : nullptr;
     a.B = B; a.chunks = chunks;
     const size_t lds = (size_t)range * sizeof(unsigned long long) + 2 * (BWD_BLOCK / 64) * sizeof(uint32_t) + 16;
-    static unsigned char lds_ok[2][64];
+    static fr_lds_flags_t lds_ok[2][64];
     if (packed) {
         if ((long long)B * chunks > 0x7FFFFFFFll) return FR_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(bwd_records_kernel, dim3((unsigned)(B * chunks)), dim3(256), 0, stream, a, rec, partial, chunks);
