@@ -297,3 +297,20 @@ def test_ring_decode_kernel_keeps_its_stream_in_registers(source, prefix, min_ke
         assert len(loads) >= 48
         for li in loads:
             assert all(not (0 < li - r <= 8) for r in valu_sgpr), (lines[si][:80], li)
+
+
+def test_fused_decode_backward_keeps_its_streams_in_registers():
+    """bwd_fused_kernel counts its inline-asm loads by hand too (tile: vmcnt(3 CB); a coordinate's fragments: vmcnt(5 CB + 12) /
+    vmcnt(5 CB)): no instantiation may spill or touch scratch (a run-time ring index once put the whole fragment ring there)."""
+    import subprocess
+    h = pkg("_lib")
+    src = os.path.join(h._CSRC, "fr_decode_bwd.hip")
+    cmd = [h._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", "--cuda-device-only",
+           "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, src]
+    out = subprocess.run(cmd, cwd=h._CSRC, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = [b for b in re.split(r"remark: Function Name: ", out.stderr)[1:] if b.startswith("_ZN2fr16bwd_fused_kernel")]
+    assert len(blocks) == 8            # NB = 1..4 live column blocks x CB = 2 / 4 coefficient blocks per wave
+    for b in blocks:
+        assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", b), b[:400]
+        assert re.search(r"VGPRs Spill: 0\b", b), b[:400]
