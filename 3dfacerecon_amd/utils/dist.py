@@ -93,7 +93,9 @@ def device_identity(device="cpu"):
         ident["pci"] = "%04x:%02x:%02x" % tuple(bus) if all(b is not None for b in bus) else None
         uuid = getattr(pr, "uuid", None)
         ident["uuid"] = str(uuid) if uuid is not None else None
-        ident["id"] = "%s/%s" % (ident["host"], ident["uuid"] or ident["pci"] or ident["device"])
+        # (bus id AND uuid: a runtime that reports the same placeholder uuid for every GPU must not make distinct devices look
+        # shared -- under nccl that raises -- and the device ordinal stands in when neither is exposed)
+        ident["id"] = "%s/pci=%s/uuid=%s" % (ident["host"], ident["pci"] or ident["device"], ident["uuid"] or "-")
     else:
         ident.update(device="cpu", name="cpu", pci=None, uuid=None, id="%s/cpu-pid%d" % (ident["host"], ident["pid"]))
     return ident
