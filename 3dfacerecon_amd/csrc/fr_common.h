@@ -115,6 +115,7 @@ enum Opt {
     OPT_FUSED_ALONE,    // FR_FUSED_ALONE    1 = a lone emit / resolve phase of the pipelined entry also runs through the fused kernel (probe)
     OPT_BWD_CHUNKS,     // FR_BWD_CHUNKS     row chunks (workgroups, partial slabs) of the packed decode-backward GEMM: 256 (default: one workgroup per CU), 1 .. 512
     OPT_BWD_CB,         // FR_BWD_CB         16-coefficient blocks per wave of the fused decode backward: 0 = by batch (default) | 2 | 4
+    OPT_EMIT_ORDER,     // FR_EMIT_ORDER     lane order of a segment's triangles: -1 scored per segment (default), 0 identity, 1 even / odd passes
     OPT_COUNT
 };
 int opt(Opt o);

@@ -61,7 +61,8 @@ struct RenderArgs {
     uint32_t rows_magic;   // ceil(2^32 / rows): y / rows == umulhi(y, magic) for y, rows < 2^16
     int resolve_opt;       // A/B knob FR_RESOLVE_OPT: 1 = single-trip bins keep records + normals in registers
     int use_filter;        // A/B knob FR_EMIT_FILTER: 0 sends every pixel through the fp64 sequence
-    const int4* tri4;      // [ntri] pre-validated triangles {4*p1, 4*p2, 4*p3, valid} (pack_tri_kernel)
+    const int4* tri4;      // [nseg*SEG] pre-validated triangles {4*p1, 4*p2, 4*p3, valid} by id, [1] header, [nseg*SEG] the same in
+                           // the emit kernel's lane order, .w = valid | local index << 1 (pack_tri_kernel)
     uint32_t nseg_magic;   // ceil(2^32 / nseg): lid / nseg == umulhi(lid, magic) (launcher checks the range)
 };
 
@@ -437,16 +438,72 @@ __device__ __forceinline__ bool id_ok(float f, int n, int& p) {
 // invalid (the planes come out as pure background) when the table it is handed was not packed for its (nver, ntri) --
 // a caller of the phase-by-phase entry point that skipped the pack phase, or reused the workspace for another shape,
 // gets a defined result instead of out-of-bounds gathers.
-constexpr int TRI4_MAGIC = 0x46525434;  // "FRT4"
-__global__ __launch_bounds__(256) void pack_tri_kernel(const float* __restrict__ tri, int nver, int ntri,
-                                                       int4* __restrict__ out, int4* __restrict__ hdr) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) *hdr = make_int4(TRI4_MAGIC, nver, ntri, 0);
-    if (t >= ntri) return;
-    int p1, p2, p3;
-    const bool ok = id_ok(tri[t], nver, p1) & id_ok(tri[(size_t)ntri + t], nver, p2) &
-                    id_ok(tri[2 * (size_t)ntri + t], nver, p3);
-    out[t] = ok ? make_int4(p1 << 2, p2 << 2, p3 << 2, 1) : make_int4(0, 0, 0, 0);
+constexpr int TRI4_MAGIC = 0x46525435;  // "FRT5"
+constexpr int PACK_TPT = 2;                 // (= TPT of the emit kernel, declared below: two triangles per thread)
+constexpr int PACK_ACTIVE = SEG / PACK_TPT;
+// Lane order of a segment's triangles in the emit kernel.  Thread `tid` of an emit workgroup takes the table positions
+// j = tid and j = PACK_ACTIVE + tid of its segment; WHICH triangle sits at a position is free (records carry the triangle's id,
+// the resolve is order-independent), and it decides what the gathers cost: the CU's address path serves a dword gather at
+// 16 lanes per clock when neighbouring lanes read neighbouring dwords, and at 4 lanes per clock or worse when they alternate
+// between two rows (tools/gather_rate_probe.hip: 2.1 against 7.0 ns per wave instruction).  A triangle list that walks a grid
+// cell by cell -- (v00, v10, v01), (v01, v10, v11), next cell -- makes every second lane jump a row under the identity order;
+// taking the even triangles in the first pass and the odd ones in the second makes all eighteen streams consecutive.  The
+// candidate orders are scored per segment by the number of neighbouring-lane pairs that do NOT read neighbouring dwords.
+__device__ __forceinline__ int perm_local(int c, int j) {
+    const int u = j >= PACK_ACTIVE ? 1 : 0, tid = j - u * PACK_ACTIVE;
+    return c == 1 ? 2 * tid + u : j;
+}
+constexpr int PACK_NCAND = 2;
+// One workgroup per segment.  out[t] (by triangle id, what the resolver and the per-face texture path read) =
+// {4*p1, 4*p2, 4*p3, valid}; outp[seg * SEG + j] (by position, what the emit kernel's phase A reads) = the same offsets with
+// .w = valid | local index << 1.  Both are defined for all nseg * SEG slots (invalid beyond ntri).
+__global__ __launch_bounds__(256) void pack_tri_kernel(const float* __restrict__ tri, int nver, int ntri, int4* __restrict__ out,
+                                                       int4* __restrict__ hdr, int4* __restrict__ outp, int force) {
+    __shared__ int po[3][SEG];
+    __shared__ unsigned char okf[SEG];
+    __shared__ uint32_t cost[PACK_NCAND];
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    if (seg == 0 && tid == 0) *hdr = make_int4(TRI4_MAGIC, nver, ntri, 0);
+    if (tid < PACK_NCAND) cost[tid] = 0;
+    for (int i = tid; i < SEG; i += 256) {
+        const int t = seg * SEG + i;
+        int p1 = 0, p2 = 0, p3 = 0;
+        bool ok = false;
+        if (t < ntri)
+            ok = id_ok(tri[t], nver, p1) & id_ok(tri[(size_t)ntri + t], nver, p2) & id_ok(tri[2 * (size_t)ntri + t], nver, p3);
+        const int4 e = ok ? make_int4(p1 << 2, p2 << 2, p3 << 2, 1) : make_int4(0, 0, 0, 0);
+        out[t] = e;
+        po[0][i] = e.x; po[1][i] = e.y; po[2][i] = e.z;
+        okf[i] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    for (int j = tid; j < SEG; j += 256) {
+        const int tl = j >= PACK_ACTIVE ? j - PACK_ACTIVE : j;
+        if (tl & 15) {   // neighbours inside a 16-lane group
+#pragma unroll
+            for (int c = 0; c < PACK_NCAND; c++) {
+                const int ia = perm_local(c, j), ib = perm_local(c, j - 1);
+                uint32_t br = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int d = po[k][ia] - po[k][ib];
+                    br += (d > 4 || d < -4) ? 1u : 0u;
+                }
+                if (br) atomicAdd(&cost[c], br);
+            }
+        }
+    }
+    __syncthreads();
+    int c = 0;
+    uint32_t best = cost[0];
+#pragma unroll
+    for (int k = 1; k < PACK_NCAND; k++)
+        if (cost[k] < best) { best = cost[k]; c = k; }   // ties: the lower-numbered order
+    if (force >= 0 && force < PACK_NCAND) c = force;      // A/B knob FR_EMIT_ORDER
+    for (int j = tid; j < SEG; j += 256) {
+        const int i = perm_local(c, j);
+        outp[(size_t)seg * SEG + j] = make_int4(po[0][i], po[1][i], po[2][i], (int)okf[i] | (i << 1));
+    }
 }
 __device__ __forceinline__ float ld_boff(const float* __restrict__ base, int boff) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)(uint32_t)boff);
@@ -540,13 +597,16 @@ __device__ __forceinline__ void emit_body(const RenderArgs& a, const int lid, un
         int4 e[TPT];
         float x1[TPT], x2[TPT], x3[TPT], y1[TPT], y2[TPT], y3[TPT], z1[TPT], z2[TPT], z3[TPT];
         bool valid[TPT];
+        // the segment's triangles in the lane order pack_tri_kernel chose: position -> {offsets, valid | local index << 1}
+        const int4* __restrict__ tri4p = a.tri4 + ((size_t)a.nseg * SEG + 1) + (size_t)seg * SEG;
+        int tl[TPT];
 #pragma unroll
         for (int u = 0; u < TPT; u++) {
-            const int t = seg * SEG + u * EMIT_ACTIVE + tid;
             // one unconditional 16-byte load (saddr + 32-bit offset form); no short-circuit on .w, or the compiler
             // splits the load and serialises the two halves
-            e[u] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.tri4) + (size_t)((uint32_t)min(t, ntri - 1) << 4));
-            valid[u] = ((int)(tid < EMIT_ACTIVE) & (int)(t < ntri) & e[u].w & table_ok) != 0;
+            e[u] = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(tri4p) + (size_t)((uint32_t)min(u * EMIT_ACTIVE + tid, SEG - 1) << 4));
+            valid[u] = ((int)(tid < EMIT_ACTIVE) & e[u].w & table_ok) != 0;   // (a valid entry has t < ntri: pack_tri_kernel)
+            tl[u] = e[u].w >> 1;
         }
         if constexpr (PR::abl == 2) {   // (ablation: the table loads only)
             if (e[0].x + e[1].y == 0x7fffffff) qd[tid].x = 1;
@@ -604,7 +664,7 @@ __device__ __forceinline__ void emit_body(const RenderArgs& a, const int lid, un
                     const float* tj = a.texture + (size_t)j * nver;
                     tm[j] = div3((ld_boff(tj, e[u].x) + ld_boff(tj, e[u].y)) + ld_boff(tj, e[u].z));
                 }
-                a.tritex_ws[seg * SEG + u * EMIT_ACTIVE + tid] = make_float4(tm[0], tm[1], tm[2], 0.0f);
+                a.tritex_ws[seg * SEG + tl[u]] = make_float4(tm[0], tm[1], tm[2], 0.0f);
             }
         }
         pr.template stamp<1>();   // gathers back, bbox + pre-cull done
@@ -634,7 +694,7 @@ __device__ __forceinline__ void emit_body(const RenderArgs& a, const int lid, un
                                                 : (uint32_t)(SEG - 1) - (bbase + (u ? cm0 : 0u) + rank);
                 qa[slot] = make_float4(x1[u], y1[u], x2[u], y2[u]);
                 qb[slot] = make_float4(x3[u], y3[u], z1[u], z2[u]);
-                qd[slot] = make_uint2(__float_as_uint(z3[u]), (uint32_t)(u * EMIT_ACTIVE + tid));
+                qd[slot] = make_uint2(__float_as_uint(z3[u]), (uint32_t)tl[u]);
             }
         }
     }
@@ -1629,7 +1689,7 @@ RenderGeom render_geom(int B, int ntri, int H, int W, int rows_override) {
     g.recs_bytes = (size_t)B * g.nseg * fr::SEG * sizeof(uint4);
     g.segoff_bytes = (size_t)B * g.nseg * fr::OFF_STRIDE * sizeof(uint16_t);
     g.nrm_bytes = (size_t)B * g.nseg * fr::SEG * sizeof(float4);  // per-record normals; also bounds the tritex table
-    g.tri4_bytes = ((size_t)g.nseg * fr::SEG + 1) * sizeof(int4);  // pre-validated triangle table + its header slot
+    g.tri4_bytes = (2 * (size_t)g.nseg * fr::SEG + 1) * sizeof(int4);  // triangle table by id + header slot + the table in lane order
     // An 8x4 hit window may touch at most TWO strips (its own bucket or the boundary bucket between them): with strips
     // shorter than the window (a very wide image, or the override) it could span three and the emit kernel's bucket
     // choice would drop hits -- such shapes take the scan path instead.
@@ -1784,8 +1844,8 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     }
     if (phases & 4) {
         int4* tri4 = const_cast<int4*>(a.tri4);
-        hipLaunchKernelGGL(pack_tri_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, tri, nver, ntri, tri4,
-                           tri4 + (size_t)g.nseg * SEG);
+        hipLaunchKernelGGL(pack_tri_kernel, dim3((unsigned)g.nseg), dim3(256), 0, stream, tri, nver, ntri, tri4,
+                           tri4 + (size_t)g.nseg * SEG, tri4 + (size_t)g.nseg * SEG + 1, opt(OPT_EMIT_ORDER));
     }
     if (phases & 1)
         hipLaunchKernelGGL(raster_emit_kernel<NoEmitProbe>, dim3((unsigned)((long long)B * g.nseg)), dim3(EMIT_BLOCK), 0, stream, a);
@@ -1856,8 +1916,8 @@ int fr_launch_render_pipelined(const float* vertex, const float* vertex_prev, lo
     const long long n_emit = (long long)B * g.nseg, n_res = (long long)B * g.strips;
     if (phases & 4) {
         int4* tri4 = const_cast<int4*>(ae.tri4);
-        hipLaunchKernelGGL(pack_tri_kernel, dim3((unsigned)((ntri + 255) / 256)), dim3(256), 0, stream, tri, nver, ntri, tri4,
-                           tri4 + (size_t)g.nseg * SEG);
+        hipLaunchKernelGGL(pack_tri_kernel, dim3((unsigned)g.nseg), dim3(256), 0, stream, tri, nver, ntri, tri4,
+                           tri4 + (size_t)g.nseg * SEG, tri4 + (size_t)g.nseg * SEG + 1, opt(OPT_EMIT_ORDER));
     }
     const bool alone = opt(OPT_FUSED_ALONE) != 0 && (phases & 3) != 0;   // probe: a single role through the fused kernel
     if ((phases & 3) == 3 || alone) {

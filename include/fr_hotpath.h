@@ -51,6 +51,8 @@ const char* fr_strerror(int code);
  *   FR_BWD_CHUNKS (row chunks of the packed decode-backward GEMM: 256 = default | 1 .. 512; changes the association of the
  *   partial sums, i.e. the gradient's last bits -- every other knob leaves every result bit unchanged)
  *   FR_BWD_CB (16-coefficient blocks per wave of the fused decode backward: 0 = by batch | 2 | 4)
+ *   FR_EMIT_ORDER (lane order of a segment's triangles in the emit kernel, fixed by the pack phase: -1 = scored per segment
+ *   (default) | 0 = list order | 1 = even triangles, then odd ones; read when the triangle list is packed)
  * None of them changes a result bit (tests/test_render_gpu.py, tests/test_decode_gpu.py hold every setting to the oracle).
  * Returns FR_OK or FR_ERR_INVALID_ARG (unknown name). */
 int fr_set_option(const char* name, int value);
@@ -74,7 +76,8 @@ int fr_render_depth_forward(const float* vertex, const float* tri, const float* 
                             float* normal, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream);
 
 /* The forward op phase by phase.  It is three launches: pack_tri_kernel (phase bit 4) converts and range-checks the
- * float-stored triangle list once into a table in the workspace; raster_emit_kernel (bit 1) writes per-strip hit
+ * float-stored triangle list once into a table in the workspace (twice: by triangle id, and per 504-triangle segment in the
+ * lane order that makes the emit kernel's gathers cheapest for this list); raster_emit_kernel (bit 1) writes per-strip hit
  * records into the workspace; resolve_write_kernel (bit 2) turns them into the four planes.  phases = 7 is
  * fr_render_depth_forward.  A caller whose triangle list is a constant of the model (the reference makes it a
  * tf.constant, nets/network.py:178) and whose workspace persists may pack once (phases = 4) and then run phases = 3

@@ -56,7 +56,7 @@ def test_validation_codes_without_gpu():
     seg = 504  # triangles (= record slots) per segment
     nseg = (105840 + seg - 1) // seg
     assert L.fr_render_depth_workspace_bytes(64, 53215, 105840, 200, 200) == \
-        64 * nseg * (seg * 16 + 64 * 2) + 2 * 64 * nseg * seg * 16 + (nseg * seg + 1) * 16  # + triangle table + its header
+        64 * nseg * (seg * 16 + 64 * 2) + 2 * 64 * nseg * seg * 16 + (2 * nseg * seg + 1) * 16  # + triangle table by id + its header + the table in lane order
     assert L.fr_render_depth_workspace_bytes(0, 5, 5, 8, 8) == 0
     # workspace too small
     assert L.fr_render_depth_forward(one, one, one, 1, 3, 1, 4, 4, 3, 1, one, one, one, one, nul, 0, nul) == -2
