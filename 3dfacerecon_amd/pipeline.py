@@ -33,10 +33,12 @@ def _host():
 
 
 class DecodeRenderPlan:
-    def __init__(self, net, batch, height=None, width=None, texture=None):
+    def __init__(self, net, batch, height=None, width=None, texture=None, stream=None):
         """net: nets.network.FaceRecNet (holds the packed basis, tri, vertex_code); texture: (3,N) or (B,3,N)
-        tensor, default net.vertex_code (the PNCC colour code, reference network.py:116)."""
+        tensor, default net.vertex_code (the PNCC colour code, reference network.py:116).  stream: a torch.cuda.Stream
+        every launch of this plan goes to (default: whatever torch's current stream is at the call)."""
         h = _host()
+        self.stream = stream
         self._h = h
         self._L = L = h.lib()
         self.net = net
@@ -90,7 +92,8 @@ class DecodeRenderPlan:
         self.pack_tri()
 
     def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        st = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        return ctypes.c_void_p(st.cuda_stream)
 
     def _run(self, phases):
         """Phase bits of fr_decode_render_forward: 8 = decode, 4 = pack the triangle list, 1 = emit, 2 = resolve."""
@@ -138,6 +141,8 @@ class DecodeRenderPlan:
     # -- hipGraph ------------------------------------------------------------------------------------------------
     def capture(self):
         """Captures decode + render (reading self.params, writing the plan's outputs) into a hipGraph."""
+        if self.stream is not None:
+            raise RuntimeError("a plan bound to a stream launches eagerly on it; build an unbound plan to capture a hipGraph")
         with torch.cuda.device(self.device):
             self.step()  # warm-up launch outside the capture (function attributes, lazy module load)
             torch.cuda.synchronize(self.device)
@@ -154,6 +159,79 @@ class DecodeRenderPlan:
             self.params.copy_(params.reshape(self.B, -1), non_blocking=True)
         self._graph.replay()
         return self.outputs()
+
+
+class BatchesInFlight:
+    """S (default two) independent batches in flight: S DecodeRenderPlans -- each with its own parameters, vertex buffer,
+    workspace and output planes -- each bound to its own HIP stream, with NO edge between the streams.  `submit()` sends the
+    next batch down the next slot's stream (round robin) and returns that slot.  Consecutive batches of a serving loop are
+    independent (render_depth_op.cc:180 loops over them one after the other only because it is a serial program), so the
+    hardware may run the decode of one beside the render of the other: one batch's kernels fill the tails, launch gaps and
+    idle units of the other's.  Measured on an MI355X at 64 faces: 100-103 us per batch against 110 us for one plan stepping
+    on one stream (tools/multistream_probe.py; three in flight: slower again -- the batches' working sets evict each other
+    from the 256 MiB Infinity Cache).  The first slot's stream has the higher priority: without it the two streams'
+    kernels share the chip evenly and every kernel runs in the other's shadow; with it one batch runs ahead and the other
+    fills in (-4 us).
+
+    Rules of use: a slot's outputs are complete when ITS stream has run dry (`slot.wait()`, or
+    `slot.make_current_stream_wait()` to order a consumer on torch's current stream behind it) and are overwritten when the
+    slot comes round again (S submits later).  `submit(params)` copies `params` into the slot's buffer on the slot's stream
+    after making that stream wait for torch's current stream (the producer of `params`)."""
+
+    def __init__(self, net, batch, height=None, width=None, texture=None, slots=2):
+        if int(slots) < 1:
+            raise ValueError("slots must be >= 1")
+        self.device = net.device
+        with torch.cuda.device(self.device):
+            lo, hi = -1, 0
+            self.slots = []
+            for i in range(int(slots)):
+                st = torch.cuda.Stream(device=self.device, priority=(lo if i == 0 else hi))
+                self.slots.append(_Slot(net, batch, height, width, texture, stream=st))
+            torch.cuda.synchronize(self.device)   # every slot's triangle table is packed before anything else touches the slots
+        self._next = 0
+        self.B = self.slots[0].B
+
+    def submit(self, params=None, marks=None):
+        """Launches decode + render of one batch on the next slot's stream; returns the slot (a DecodeRenderPlan).
+        marks: four torch.cuda.Events to record on the slot's stream before the decode, between the three launches and
+        after the resolve (bench.py's per-kernel timing; the step then goes out as three C calls instead of one)."""
+        sl = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        if params is not None:
+            sl.stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(sl.stream):
+                sl.params.copy_(params.reshape(sl.B, -1), non_blocking=True)
+        if marks is None:
+            sl._run(11)
+        else:
+            marks[0].record(sl.stream)
+            sl._run(8)
+            marks[1].record(sl.stream)
+            sl._run(1)
+            marks[2].record(sl.stream)
+            sl._run(2)
+            marks[3].record(sl.stream)
+        return sl
+
+    def synchronize(self):
+        for sl in self.slots:
+            sl.stream.synchronize()
+
+    def __del__(self):   # the slots' buffers go back to torch's allocator: not while their streams still run
+        try:
+            self.synchronize()
+        except Exception:
+            pass
+
+
+class _Slot(DecodeRenderPlan):
+    def wait(self):
+        self.stream.synchronize()
+        return self.outputs()
+
+    def make_current_stream_wait(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
 
 class PipelinedPlan:

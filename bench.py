@@ -142,7 +142,7 @@ def cpu_baseline(assets, params_np, n_faces, H, W, synth):
     }
 
 
-def parity_gate(plan, net, assets, params_np, H, W, n_faces):
+def parity_gate(plan, net, assets, params_np, H, W, n_faces, run=True):
     """The timed route's own buffers against the CPU oracle, on the first `n_faces` faces of this rank's batch.
       * render: oracle rasteriser (render_depth_op.cc:132-322 restated) on the PLAN'S vertex_proj -> all four planes
         bit for bit (a NaN equals a NaN);
@@ -163,7 +163,7 @@ def parity_gate(plan, net, assets, params_np, H, W, n_faces):
         plan.submit()
         plan.submit()
         torch.cuda.synchronize(plan.device)
-    else:
+    elif run:
         plan.step()
     torch.cuda.synchronize(plan.device)
     V = plan.vertex_proj[:n].contiguous().cpu().numpy()   # (the plan hands the vertices over in pitched rows: a strided view)
@@ -238,8 +238,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="faces per GPU per step")
     ap.add_argument("--im-size", type=int, default=200)
     ap.add_argument("--repeats", type=int, default=0,
-                    help="timed K-step blocks; the median block is reported.  0 = auto: max(10, 600 // K) -- the first "
-                         "~15 ms of GPU work after the host-side set-up run on a chip that is still ramping its clock "
+                    help="timed K-step blocks; the median block is reported.  0 = auto: max(10, 1600 // K) -- the first "
+                         "~30 ms of GPU work after the host-side set-up run on a chip that is still ramping its clock "
                          "(blocks_ms_per_step in the line shows it), so the blocks have to span well beyond that for "
                          "the median to be a steady-state block")
     ap.add_argument("--cpu-faces", type=int, default=2048, help="faces in the cpu_baseline sample (0 = skip); 2048 ~ 10 s")
@@ -250,11 +250,13 @@ def main():
                     help="faces per rank the oracle checks before the line is printed (-1 = all of them; 0 = skip, the "
                          "line then carries parity = null and must not be quoted)")
     ap.add_argument("--no-ops-surface", action="store_true", help="skip the operator-surface leg")
-    ap.add_argument("--route", choices=("auto", "pipelined", "serial"), default="auto",
-                    help="pipelined: PipelinedPlan (two batches in flight: decode, then emit(k) || resolve(k-1) in one "
-                         "launch; every timed block runs K submits + the drain, i.e. K batches from parameters to planes); "
-                         "serial: DecodeRenderPlan (three launches per batch).  auto = serial (measured faster, DESIGN.md 4.6)")
-    ap.add_argument("--no-serial-leg", action="store_true", help="skip the serial plan's comparison leg (pipelined route)")
+    ap.add_argument("--route", choices=("auto", "inflight", "pipelined", "serial"), default="auto",
+                    help="inflight: BatchesInFlight (--in-flight independent batches, each on its own stream, no edge between "
+                         "them: consecutive steps go to alternating slots); serial: DecodeRenderPlan (one batch at a time, three "
+                         "launches per batch on one stream); pipelined: PipelinedPlan (decode, then emit(k) || resolve(k-1) in "
+                         "one launch; measured slower, DESIGN.md 4.6).  auto = inflight (measured fastest, DESIGN.md 4.7)")
+    ap.add_argument("--in-flight", type=int, default=2, help="slots of the inflight route (2 measured best; 3 is slower again)")
+    ap.add_argument("--no-serial-leg", action="store_true", help="skip the serial plan's comparison leg (inflight / pipelined routes)")
     ap.add_argument("--allreduce-mb", type=float, default=-1.0,
                     help="N > 1: time one SUM all-reduce of this many MB on the bench's process group before the timed "
                          "region (config 4's gradient is ~302 MB) and report bus GB/s.  -1 = 302 under nccl, 4 under gloo; 0 = skip")
@@ -306,16 +308,28 @@ def main():
     # auto = the faster route on this hardware: the serial plan (the fused emit || resolve launch measured 112-120 us per step
     # against 111 us: the two roles bind on the same per-CU vector-memory path and do not overlap)
     piped = piped_ok and args.route == "pipelined"
+    inflight = args.route in ("auto", "inflight") and not net._basis.use_q30()
     serial_plan = pipe.DecodeRenderPlan(net, B, H, W)
     serial_plan.params.copy_(torch.as_tensor(params_np, device=dev))
     plan = serial_plan
+    slot_params = [params_np]
     if piped:
         plan = pipe.PipelinedPlan(net, B, H, W)
         plan.params.copy_(torch.as_tensor(params_np, device=dev))
+    elif inflight:
+        # every slot its own batch: slot 0 the rank's batch above, slot i another draw of the same sampler
+        plan = pipe.BatchesInFlight(net, B, H, W, slots=max(1, args.in_flight))
+        for i in range(1, len(plan.slots)):
+            if args.scaling == "strong":
+                slot_params.append(synth.sample_params_batch(args.batch, im_size=H, beta=0.7, seed=3456 + 1000 * i)[first:first + B])
+            else:
+                slot_params.append(synth.sample_params_batch(B, im_size=H, beta=0.7, seed=3456 + rank + 1000 * i))
+        for sl, pn in zip(plan.slots, slot_params):
+            sl.params.copy_(torch.as_tensor(pn, device=dev))
     torch.cuda.synchronize(dev)
 
     K, Wm = args.steps, args.warmup
-    R = args.repeats if args.repeats > 0 else max(10, 600 // max(1, K))
+    R = args.repeats if args.repeats > 0 else max(10, 1600 // max(1, K))
     # N > 1: one all-reduce of config 4's gradient size on the bench's own process group, before anything is timed
     ar_mb = args.allreduce_mb
     if ar_mb < 0:
@@ -334,8 +348,9 @@ def main():
     EV_EVERY, EV_FIRST = 10, 5   # steps 5, 15, 25, ...: never the block's first step (it starts on an idle chip)
 
     def timed_blocks(pl, is_piped, with_events):
+        is_fl = hasattr(pl, "slots")
         for _ in range(Wm):
-            pl.submit() if is_piped else pl.step()
+            pl.submit() if (is_piped or is_fl) else pl.step()
         if is_piped:
             pl.flush()
         # (events for every block are created up front and the per-block max over ranks is taken after the last block, so
@@ -350,7 +365,9 @@ def main():
             t0 = time.perf_counter()
             for k in range(K):
                 e = ev.get(k)
-                if e is None:
+                if is_fl:        # step k goes to slot k mod S, on that slot's stream; the events are recorded on that stream
+                    pl.submit(marks=e)
+                elif e is None:
                     pl.submit() if is_piped else pl.step()
                 elif is_piped:   # the same two launches, each bracketed by events
                     e[0].record()
@@ -385,8 +402,9 @@ def main():
 
     # the serial plan (three launches per batch, nothing in flight across batches) in the same process, same K / W / R
     serial_elapsed = None
-    if piped and not args.no_serial_leg:
-        _, serial_elapsed, _, _ = timed_blocks(serial_plan, False, False)
+    serial_ev = []
+    if (piped or inflight) and not args.no_serial_leg:
+        _, serial_elapsed, _, serial_ev = timed_blocks(serial_plan, False, inflight)
 
     # the operator-surface route (allocations + pack_tri every call): same K / W / R, reported beside `value`
     ops_elapsed = ops_same = None
@@ -397,7 +415,29 @@ def main():
     # parity gate: the oracle on every face of the timed route's buffers, on every rank
     parity = None
     if args.parity_faces != 0:
-        parity = parity_gate(plan, net, assets, params_np, H, W, B if args.parity_faces < 0 else args.parity_faces)
+        nf = B if args.parity_faces < 0 else args.parity_faces
+        if inflight:
+            # several batches deep on every slot, all slots running beside each other; then every slot's vertices and planes
+            # against the oracle on that slot's own parameters
+            for _ in range(3 * len(plan.slots)):
+                plan.submit()
+            plan.synchronize()
+            per_slot = [parity_gate(sl, net, assets, pn, H, W, nf, run=False) for sl, pn in zip(plan.slots, slot_params)]
+            parity = dict(per_slot[0])
+            parity["route"] = ("BatchesInFlight: %d slots (DecodeRenderPlans, fr_decode_render_forward, phases 8|1|2), each on its own "
+                               "stream; checked after %d submits that ran beside each other" % (len(plan.slots), 3 * len(plan.slots)))
+            parity["batches_checked"] = len(per_slot)
+            parity["faces_checked"] = sum(q["faces"] for q in per_slot)
+            parity["planes_checked"] = sum(q["planes_checked"] for q in per_slot)
+            parity["mismatching_planes"] = sum(q["mismatching_planes"] for q in per_slot)
+            parity["decode_host_rotation_mismatching_faces"] = sum(q["decode_host_rotation_mismatching_faces"] for q in per_slot)
+            parity["decode_inkernel_rotation"] = {
+                "max_ulp": max(q["decode_inkernel_rotation"]["max_ulp"] for q in per_slot),
+                "frac_bit_equal": min(q["decode_inkernel_rotation"]["frac_bit_equal"] for q in per_slot),
+                "bar": per_slot[0]["decode_inkernel_rotation"]["bar"]}
+            parity["ok"] = bool(all(q["ok"] for q in per_slot))
+        else:
+            parity = parity_gate(plan, net, assets, params_np, H, W, nf)
         if piped:   # and the two routes against each other: every plane of every face, bit for bit
             serial_plan.step()
             plan.step()
@@ -414,6 +454,7 @@ def main():
             dist_u.finalize()
             sys.exit(3)
     decode_ms = sum(e[0].elapsed_time(e[1]) for e in ev_all) / len(ev_all)
+    in_region = None
     if piped:
         fused_ms = sum(e[1].elapsed_time(e[2]) for e in ev_all) / len(ev_all)
         emit_ms = resolve_ms = None
@@ -421,7 +462,16 @@ def main():
         emit_ms = sum(e[1].elapsed_time(e[2]) for e in ev_all) / len(ev_all)
         resolve_ms = sum(e[2].elapsed_time(e[3]) for e in ev_all) / len(ev_all)
         fused_ms = None
-    cov = float((plan.tri_ind >= 0).float().mean().item())
+    cov = float(((plan.slots[0] if inflight else plan).tri_ind >= 0).float().mean().item())
+    if inflight and serial_ev:
+        # Two batches in flight: a kernel's event-bracketed duration in THAT region measures how the two streams share the
+        # chip (a kernel of the low-priority stream waits for the other batch's workgroups), not the kernel.  The per-kernel
+        # figures and the roofline object therefore come from the serial leg of this same process -- the same kernels, same
+        # K / W / R and brackets, one batch in flight -- and the in-region durations ride along as `in_region_avg_ms`.
+        in_region = {"decode": decode_ms, "raster_emit": emit_ms, "resolve_write": resolve_ms}
+        decode_ms = sum(e[0].elapsed_time(e[1]) for e in serial_ev) / len(serial_ev)
+        emit_ms = sum(e[1].elapsed_time(e[2]) for e in serial_ev) / len(serial_ev)
+        resolve_ms = sum(e[2].elapsed_time(e[3]) for e in serial_ev) / len(serial_ev)
 
     graph_fps = None
     if args.graph:   # (the serial plan: three kernel nodes per replay)
@@ -445,11 +495,17 @@ def main():
         # owns the vertex / triangle / texture reads, the resolve kernel the four output planes
         emit_bytes = (4.0 * 3 * N + (4.0 * 3 * T + 4.0 * 3 * N) / B) * B
         resolve_bytes = 4.0 * H * W * 8 * B
-        q30 = plan.q30   # FR_DECODE_ARITH=q30 (opt-in, frozen experiment; the default is the f32 chain)
+        q30 = serial_plan.q30   # FR_DECODE_ARITH=q30 (opt-in, frozen experiment; the default is the f32 chain)
         ev_note = ("HIP events on the launch stream around each launch of every %dth step of the timed blocks (the step then goes "
                    "out launch by launch: separate C calls + event bubbles): an UPPER bound of the kernel's duration in the "
                    "un-bracketed steps; the rocprofv3 average of the same kernel is `rocprofv3_avg_ms` "
                    "(profiles/round4_kernel_stats.csv, a PROFILED run: slower clock)" % EV_EVERY)
+        if in_region is not None:
+            ev_note += ("; taken in the SERIAL leg of this process (one plan, one stream, one batch in flight; its throughput is "
+                        "`serial_plan_faces_per_s`): with two batches in flight a kernel's bracketed duration measures how the two "
+                        "streams share the chip, not the kernel -- those durations are `in_region_avg_ms`")
+        elif inflight:
+            ev_note += "; TWO batches in flight and no serial leg (--no-serial-leg): the durations include the time the kernel waits for or shares the chip with the other batch's kernels"
         if q30:   # int8-MFMA blend: the matrix pipe is no longer the bound, the 153 MB basis + 41 MB output stream is
             roof_decode = {"bound": "hbm", "kernel": "q_stage_kernel + decode_q_ring_kernel<16,4,8> (fr_decode_3dmm, Q30)",
                            "achieved": ab["decode"] * B / (decode_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -499,9 +555,11 @@ def main():
                             r["rocprofv3_avg_ms"] = rec["rocprofv3_avg_ms"]
         except (OSError, ValueError, KeyError):
             pass
-        for r in kernels.values():
+        for name, r in kernels.items():
             r["frac"] = r["achieved"] / r["peak"]
             r["avg_ms_is"] = ev_note
+            if in_region is not None and name in in_region:
+                r["in_region_avg_ms"] = in_region[name]
         dominant = max(kernels.values(), key=lambda r: r["avg_ms"])  # the kernel with the longest average launch
         if not piped:
             render_ms = emit_ms + resolve_ms
@@ -512,7 +570,11 @@ def main():
         route = ("pipelined: PipelinedPlan / fr_decode_render_pipelined -- per step TWO launches: decode(k), then ONE launch "
                  "whose blocks are the emit role of batch k or the (lean) resolve role of batch k-1; a timed block = K "
                  "submits + the drain, so K batches go from parameters to planes inside the brackets") if piped else \
-                "serial: DecodeRenderPlan / fr_decode_render_forward -- three launches per batch"
+                ("inflight: BatchesInFlight -- %d independent batches in flight, each slot a DecodeRenderPlan "
+                 "(fr_decode_render_forward, three launches per batch) on its own stream with no edge between the streams; step k "
+                 "goes to slot k mod %d; a timed block = K such steps, i.e. K batches from parameters to planes between the "
+                 "brackets (both streams drained at either bracket)" % (len(plan.slots), len(plan.slots))) if inflight else \
+                "serial: DecodeRenderPlan / fr_decode_render_forward -- three launches per batch, one batch at a time"
         out = {
             "metric": "faces/sec (3DMM decode+depth render), batch 64 @200x200",
             "value": value, "unit": "faces/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -525,7 +587,7 @@ def main():
             "config": {"workload": "configs[1]: batch %d random 235-d params -> 3DMM decode -> depth render, "
                                    "%dx%d, fp32, all four output planes" % (args.batch, H, W),
                        "faces_per_gpu": B if args.scaling == "weak" else None, "faces_per_step_all_gpus": faces_per_step,
-                       "faces_per_gpu_rank0": B, "nver": N, "ntri": T, "n_shape": net.ndim_shape, "n_exp": net.ndim_exp,
+                       "faces_per_gpu_rank0": B, "batches_in_flight": len(plan.slots) if inflight else (2 if piped else 1), "nver": N, "ntri": T, "n_shape": net.ndim_shape, "n_exp": net.ndim_exp,
                        "sampler": "sample_test.py:23-38 beta=0.7 " + ("seed=3456+rank" if args.scaling == "weak" else "seed=3456, one batch for all ranks"), "coverage": cov,
                        "sharding": ("weak: every rank runs its own %d faces" % B if args.scaling == "weak" else
                                     "strong: ONE %d-face batch cut into contiguous shards (utils.dist.shard_range)" % args.batch)
@@ -553,7 +615,7 @@ def main():
                                            "same `tri` tensor is passed: ops._render_phases)"}
         if serial_elapsed is not None:
             out["serial_plan_faces_per_s"] = faces_per_step * K / serial_elapsed
-            out["serial_plan"] = {"ms_per_step": 1e3 * serial_elapsed / K, "pipelined_vs_serial": serial_elapsed / elapsed,
+            out["serial_plan"] = {"ms_per_step": 1e3 * serial_elapsed / K, "timed_route_vs_serial": serial_elapsed / elapsed,
                                   "route": "DecodeRenderPlan.step(): decode -> emit -> resolve, three launches, same process, "
                                            "same K / W / R (median block)"}
         if allreduce is not None:

@@ -43,11 +43,21 @@ def test_bench_line_one_gpu():
     assert d["parity"]["ok"] and d["parity"]["faces"] == 64 and d["parity"]["mismatching_planes"] == 0
     assert d["ops_surface"]["outputs_identical_to_plan"] and d["ops_surface_faces_per_s"] > 1e4
     assert d["dist"]["world_size"] == 1 and d["config"]["faces_per_step_all_gpus"] == 64
-    # the default route is the serial plan (three launches per batch); the device the rank ran on is in the line
-    assert d["route"].startswith("serial") and {"decode", "raster_emit", "resolve_write"} <= set(d["kernels"])
+    # the default route keeps two independent batches in flight (two plans, two streams); the serial plan is timed beside it
+    assert d["route"].startswith("inflight") and {"decode", "raster_emit", "resolve_write"} <= set(d["kernels"])
+    assert d["config"]["batches_in_flight"] == 2 and d["parity"]["batches_checked"] == 2 and d["parity"]["faces_checked"] == 128
+    assert d["serial_plan_faces_per_s"] > 1e4 and d["serial_plan"]["timed_route_vs_serial"] > 0.8
+    assert all(d["kernels"][k]["in_region_avg_ms"] > 0 for k in ("decode", "raster_emit", "resolve_write"))
     assert d["dist"]["distinct_devices"] and d["dist"]["devices"][0]["name"] and d["dist"]["devices"][0]["id"]
     assert all("avg_ms_is" in d["kernels"][k] for k in ("decode", "raster_emit", "resolve_write"))
     assert "which_side_binds" in d["kernels"]["decode"]
+
+
+def test_bench_line_serial_route():
+    """--route serial: one plan, one stream, one batch at a time."""
+    d = _line([sys.executable, "bench.py"] + SHORT + ["--cpu-faces", "0", "--route", "serial", "--no-ops-surface"])
+    assert d["route"].startswith("serial") and d["config"]["batches_in_flight"] == 1 and d["parity"]["ok"]
+    assert "serial_plan" not in d and {"decode", "raster_emit", "resolve_write"} <= set(d["kernels"])
 
 
 def test_bench_line_pipelined_route():

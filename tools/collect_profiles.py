@@ -34,13 +34,14 @@ def kernel_stats(name, out):
                                  for r in hot}}
 
 
-for j in ("bench", "bench_k20", "bench_pipelined", "bench_graph", "bench_q30"):
+for j in ("bench", "bench_k20", "bench_serial", "bench_pipelined", "bench_graph", "bench_q30"):
     f = os.path.join(src, j + ".json")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.json" % (tag, j)))
 kernel_stats("prof_bench", "%s_kernel_stats.csv" % tag)
 kernel_stats("prof_bwd", "%s_decode_bwd_kernel_stats.csv" % tag)
 kernel_stats("prof_pipelined", "%s_pipelined_kernel_stats.csv" % tag)
+kernel_stats("prof_inflight", "%s_inflight_kernel_stats.csv" % tag)
 # the bench line printed by the SAME process the kernel stats come from (profiled: lower clocks, per-launch overhead)
 f = os.path.join(src, "prof_bench.log")
 if os.path.exists(f):
@@ -87,7 +88,7 @@ if os.path.exists(f):
         return (fetch_factor * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
     json.dump({
         "source": "rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- "
-                  "python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0, MI355X, "
+                  "python3 bench.py --route serial --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0, MI355X, "
                   "%s kernels (profiles/%s_pmc.json); per launch" % (tag, tag),
         "correction": "FETCH_SIZE x2 for the decode (16 B/lane streams are tallied at half), x1 for emit / resolve (gathers are "
                       "tallied in full); WRITE_SIZE exact -- calibrated in profiles/%s_pmc_calibration.json" % tag,

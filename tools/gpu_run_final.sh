@@ -25,13 +25,17 @@ leg pytest_gpu bash -c "python -m pytest tests -m gpu -q -p no:cacheprovider 2>&
 leg smoke bash -c "python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1"
 leg bench bash -c "python bench.py > $O/bench.json 2> $O/bench.err"
 leg bench_k20 bash -c "python bench.py --steps 20 --warmup 5 --cpu-faces 0 > $O/bench_k20.json 2>> $O/bench.err"
+leg bench_serial bash -c "python bench.py --route serial --cpu-faces 0 --no-ops-surface > $O/bench_serial.json 2>> $O/bench.err"
 leg bench_pipelined bash -c "python bench.py --route pipelined --cpu-faces 0 --no-ops-surface > $O/bench_pipelined.json 2>> $O/bench.err"
 leg bench_graph bash -c "python bench.py --graph --cpu-faces 0 --no-ops-surface > $O/bench_graph.json 2>> $O/bench.err"
 leg bench_q30 bash -c "FR_DECODE_ARITH=q30 python bench.py --cpu-faces 0 --no-ops-surface > $O/bench_q30.json 2>> $O/bench.err"
 # ---- rocprofv3: kernel stats + PMC passes of the same command (never --pmc together with a trace domain other than kernel-trace) --
-BCMD="python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0"
+# (BCMD = the serial route: one batch in flight, the state the line's per-kernel figures and roofline object are measured in;
+#  prof_inflight = the default command, where kernels of two batches share the chip and a kernel's duration measures the sharing)
+BCMD="python3 bench.py --route serial --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0"
 leg prof_bench bash -c "rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- $BCMD > $O/prof_bench.log 2>&1"
-leg prof_pipelined bash -c "rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pipelined -- $BCMD --route pipelined --no-serial-leg > $O/prof_pipelined.log 2>&1"
+leg prof_inflight bash -c "rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_inflight -- python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0 --no-serial-leg > $O/prof_inflight.log 2>&1"
+leg prof_pipelined bash -c "rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pipelined -- python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0 --route pipelined --no-serial-leg > $O/prof_pipelined.log 2>&1"
 leg pmc_fetch bash -c "rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -- $BCMD > $O/pmc_fetch.log 2>&1"
 leg pmc_write bash -c "rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_write -- $BCMD > $O/pmc_write.log 2>&1"
 leg pmc_sq1 bash -c "rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_sq1 -- $BCMD > $O/pmc_sq1.log 2>&1"
@@ -60,7 +64,7 @@ find $O -name "*.db" -delete
 cat $O/legs.log
 tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; python -c "
 import json
-for f in ('bench','bench_k20','bench_pipelined','bench_graph','bench_q30'):
+for f in ('bench','bench_k20','bench_serial','bench_pipelined','bench_graph','bench_q30'):
     try:
         d=json.loads(open('$O/%s.json'%f).read().strip().splitlines()[-1]); print(f, round(d['value']), d['ms_per_step'], d.get('value_min'), d.get('value_max'), {k:round(v['avg_ms']*1e3,1) for k,v in d['kernels'].items()}, d.get('graph_replay_faces_per_s'), d.get('ops_surface_faces_per_s'), d.get('serial_plan_faces_per_s'), (d.get('parity') or {}).get('ok'))
     except Exception as e: print(f, 'ERR', e)
