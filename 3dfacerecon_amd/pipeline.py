@@ -169,9 +169,9 @@ class BatchesInFlight:
     hardware may run the decode of one beside the render of the other: one batch's kernels fill the tails, launch gaps and
     idle units of the other's.  Measured on an MI355X at 64 faces: 100-103 us per batch against 110 us for one plan stepping
     on one stream (tools/multistream_probe.py; three in flight: slower again -- the batches' working sets evict each other
-    from the 256 MiB Infinity Cache).  The first slot's stream has the higher priority: without it the two streams'
-    kernels share the chip evenly and every kernel runs in the other's shadow; with it one batch runs ahead and the other
-    fills in (-4 us).
+    from the 256 MiB Infinity Cache).  The first slot's stream has high priority and the others low: at equal priority the
+    streams sometimes lock into step (both decodes, then both emits ... -- 100 to 107 us from one process to the next); with
+    one batch entitled to run ahead and the other filling in, 100.5-101.6 us (profiles/round4_probes/r4p).
 
     Rules of use: a slot's outputs are complete when ITS stream has run dry (`slot.wait()`, or
     `slot.make_current_stream_wait()` to order a consumer on torch's current stream behind it) and are overwritten when the
@@ -183,10 +183,10 @@ class BatchesInFlight:
             raise ValueError("slots must be >= 1")
         self.device = net.device
         with torch.cuda.device(self.device):
-            lo, hi = -1, 0
             self.slots = []
             for i in range(int(slots)):
-                st = torch.cuda.Stream(device=self.device, priority=(lo if i == 0 else hi))
+                # HIP stream priorities: -1 high, 0 normal, 1 low (out-of-range values are clamped by the runtime)
+                st = torch.cuda.Stream(device=self.device, priority=(-1 if i == 0 else 1))
                 self.slots.append(_Slot(net, batch, height, width, texture, stream=st))
             torch.cuda.synchronize(self.device)   # every slot's triangle table is packed before anything else touches the slots
         self._next = 0

@@ -21,7 +21,13 @@ def main():
     net = netm.FaceRecNet(mesh_data=A, batch_size=B, im_size=S, device=dev)
     plans = [pipe.DecodeRenderPlan(net, B, S, S) for _ in range(SMAX)]
     PRIO = os.environ.get("PRIO", "")
-    ss = [torch.cuda.Stream(priority=(-1 if (PRIO == "first" and i == 0) or PRIO == "all" else 0)) for i in range(SMAX)]
+    if "," in PRIO:   # explicit list: PRIO=-1,1
+        pl = [int(x) for x in PRIO.split(",")]
+        ss = [torch.cuda.Stream(priority=pl[i % len(pl)]) for i in range(SMAX)]
+    else:
+        ss = [torch.cuda.Stream(priority=(-1 if (PRIO == "first" and i == 0) or PRIO == "all" else 0)) for i in range(SMAX)]
+    print(json.dumps({"priority_range": list(torch.cuda.Stream.priority_range()) if hasattr(torch.cuda.Stream, "priority_range") else None,
+                      "priorities": [s.priority for s in ss]}))
     for i, p in enumerate(plans):
         p.params.copy_(torch.as_tensor(synth.sample_params_batch(B, im_size=S, beta=0.7, seed=3456 + i), device=dev))
         p.step()
