@@ -13,8 +13,20 @@ Architecture facts taken from the reference (nets/network.py):
 The render loop between the iterations is the MI355X hot path: FaceRecNet.vertices_transform (fr_decode_3dmm) and
 FaceRecNet.coarse_net_input (fr_rendering_layer_forward), both differentiable.
 """
-import torch
-import torch.nn as nn
+import os
+
+# MIOpen 3.5.0 on gfx950: while PyTorch's default (non-immediate) convolution path benchmarks the applicable solvers the
+# first time it sees a shape, the assembly implicit-GEMM backward-data kernel `igemm_bwd_gtcx35_nhwc_fp32_bx0_ex1_bt256x64x4_...`
+# (solver ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC) reads past the end of one of its buffers on this model's backward
+# shapes.  Inside torch's caching allocator the overrun usually lands in mapped memory and goes unnoticed; when the buffer
+# ends on the last page of a segment the process dies with "Memory access fault by GPU" (found with serialized launches +
+# AMD_LOG_LEVEL=3 on a fresh box with an empty MIOpen user database: the faulting launch is that kernel, inside
+# miopenFindConvolutionBackwardDataAlgorithm).  The solver is switched off for processes that build these nets -- MIOpen
+# reads the variable when it first checks the solver's applicability, i.e. after this import; an explicit setting wins.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
 
 
 def _conv_bn_relu(cin, cout, k, stride=1, act=True):

@@ -299,12 +299,13 @@ def test_div3_matches_division_on_every_fp32():
 @pytest.mark.parametrize("env", [{"FR_RENDER_IMPL": 1}, {"FR_RENDER_ROWS": 1}, {"FR_RENDER_ROWS": 3},
                                  {"FR_RENDER_ROWS": 7}, {"FR_EMIT_FILTER": 0}, {"FR_EMIT_FILTER": 1},
                                  {"FR_EMIT_FILTER": 2}, {"FR_RESOLVE_OPT": 0}, {"FR_RESOLVE_BLOCK": 512},
-                                 {"FR_RESOLVE_BLOCK": 1024}])
+                                 {"FR_RESOLVE_BLOCK": 1024}, {"FR_EMIT_ORDER": 0}, {"FR_EMIT_ORDER": 1}])
 def test_fallback_and_row_override_paths(oracle, env):
     """render_strip_kernel (every bin scans every triangle) is the path for shapes the binned rasteriser rejects; the
     tuning knob FR_RENDER_ROWS below the hit-window height must route there too, larger overrides
     stay binned.  The A/B knobs of the fast paths (FR_EMIT_FILTER: 0 = every pixel through the reference's fp64 sequence,
-    1 = certified fp32 test only, 2 = phase-A pre-cull only; FR_RESOLVE_OPT=0 = two-pass resolver) must not change a bit
+    1 = certified fp32 test only, 2 = phase-A pre-cull only; FR_RESOLVE_OPT=0 = two-pass resolver; FR_EMIT_ORDER: the lane
+    order of a segment's triangles forced to the list order / to even-then-odd instead of scored) must not change a bit
     either.  All bit-exact.  The knobs are set through fr_set_option (the environment is read once per process)."""
     rs = np.random.RandomState(11)
     scenes = [_random_scene(rs, 3, 300, 700, 33, 47, 2.0) + (33, 47), _random_scene(rs, 2, 400, 900, 64, 64, 6.0) + (64, 64)]
