@@ -202,6 +202,7 @@ class BatchesInFlight:
             sl.stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(sl.stream):
                 sl.params.copy_(params.reshape(sl.B, -1), non_blocking=True)
+            params.record_stream(sl.stream)   # the caller may drop `params` at once: its memory is not reused before the copy ran
         if marks is None:
             sl._run(11)
         else:
