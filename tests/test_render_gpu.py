@@ -316,6 +316,41 @@ def test_fallback_and_row_override_paths(oracle, env):
             assert_render_equal(render_gpu(ver, tri, tex, H, W), oracle.render_depth(ver, tri, tex, H, W), str(env))
 
 
+@pytest.mark.parametrize("order", ["cells", "halves", "shuffled"])
+def test_lane_order_of_the_emit_table_follows_the_list_and_changes_nothing(oracle, order):
+    """pack_tri_kernel writes every segment's triangles in the lane order that makes the emit kernel's gathers cheapest -- list
+    order, or even triangles then odd ones when the list walks the grid cell by cell -- scored per segment.  Whatever the list
+    looks like (cell by cell; all upper triangles, then all lower ones; shuffled) and whichever order is scored or forced,
+    the planes are the oracle's.  2,090 triangles: four full segments and a ragged fifth."""
+    rs = np.random.RandomState(17)
+    B, H, W, nu, nv = 3, 48, 52, 20, 56
+    gx, gy = np.meshgrid(np.linspace(-1.0, W, nv), np.linspace(-1.0, H, nu))
+    nver = nu * nv
+    ver = np.empty((B, 3, nver), np.float32)
+    for b in range(B):
+        ver[b, 0] = (gx + rs.uniform(-0.4, 0.4, gx.shape)).reshape(-1)
+        ver[b, 1] = (gy + rs.uniform(-0.4, 0.4, gy.shape)).reshape(-1)
+        ver[b, 2] = rs.uniform(-5, 5, nver)
+    iu, iv = np.meshgrid(np.arange(nu - 1), np.arange(nv - 1), indexing="ij")
+    v00 = (iu * nv + iv).reshape(-1)
+    ta, tb = np.stack([v00, v00 + nv, v00 + 1]), np.stack([v00 + 1, v00 + nv, v00 + nv + 1])
+    if order == "cells":
+        tri = np.empty((3, 2 * v00.size), np.int64)
+        tri[:, 0::2], tri[:, 1::2] = ta, tb
+    else:
+        tri = np.concatenate([ta, tb], 1)
+        if order == "shuffled":
+            tri = tri[:, rs.permutation(tri.shape[1])]
+    tri = tri.astype(np.float32)
+    assert tri.shape[1] == 2090
+    tex = rs.uniform(0, 1, (1, 3, nver)).astype(np.float32)
+    want = oracle.render_depth(ver, tri, tex, H, W)
+    assert (want[3] >= 0).mean() > 0.5
+    for forced in (-1, 0, 1):
+        with pkg("_lib").options(FR_EMIT_ORDER=forced):
+            assert_render_equal(render_gpu(ver, tri, tex, H, W), want, "%s list, FR_EMIT_ORDER=%d" % (order, forced))
+
+
 def test_very_wide_image_takes_the_scan_path(oracle):
     """W = 6000: only three rows of keys fit the CU's LDS, shorter than the 8x4 hit window -> strip-scan path."""
     rs = np.random.RandomState(5)
