@@ -539,6 +539,7 @@ def main():
             kernels["resolve_write"] = {"bound": "hbm", "kernel": "resolve_write_kernel<256> (fr_decode_render_forward, phase 2)",
                                         "achieved": resolve_bytes / (resolve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "traffic": None, "avg_ms": resolve_ms, "algorithmic_bytes_per_launch": resolve_bytes}
+        vector_pipe = None
         # HBM traffic per launch + the rocprofv3 kernel averages, from the committed profile passes of this same command
         # (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc passes; ONE stated correction for all
         # kernels -- see its `correction` field -- so the figures of one line are comparable)
@@ -553,6 +554,16 @@ def main():
                         r["traffic_source"] = "profiles/pmc_traffic.json (%s)" % pmc.get("correction", "")
                         if rec.get("rocprofv3_avg_ms") is not None:
                             r["rocprofv3_avg_ms"] = rec["rocprofv3_avg_ms"]
+                vp = pmc.get("vector_pipe")
+                if isinstance(vp, dict):   # what the step asks of the vector ALUs (f32 MFMA included: it runs there)
+                    vector_pipe = {"cycles_per_simd_per_step": vp["step_cycles_per_simd"], "us_at_2.1GHz": vp["step_us_at_2.1GHz"],
+                                   "per_kernel_cycles_per_simd": {k: vp[k]["cycles_per_simd"] for k in ("decode", "raster_emit", "resolve_write")},
+                                   "frac_of_ms_per_step": vp["step_us_at_2.1GHz"] * 1e-3 / (1e3 * elapsed / K),
+                                   "is": "PMC instruction counts of the three kernels (profiles/pmc_traffic.json: 32 cycles per "
+                                         "v_mfma_f32_16x16x4_f32, 4 per other wave64 vector instruction, per SIMD) against the measured "
+                                         "step: the share of the step the vector pipe alone accounts for.  The f32-input MFMA and every "
+                                         "other vector instruction of a SIMD take turns (profiles/round4_probes/r4t), so this pipe, not "
+                                         "HBM, is what the step is closest to"}
         except (OSError, ValueError, KeyError):
             pass
         for name, r in kernels.items():
@@ -603,6 +614,7 @@ def main():
                              "achieved_GBs": ab["pipeline"] * value / world / 1e9,
                              "frac_of_8TBs": ab["pipeline"] * value / world / 1e9 / HBM_PEAK_GBS,
                              "frac_of_measured_copy_6.29TBs": ab["pipeline"] * value / world / 1e9 / HBM_COPY_GBS},
+            "vector_pipe": vector_pipe,
             "parity": parity,
             "dist": dict(dist_info, per_rank_ms_per_step=per_rank_ms, launcher_world_size=world),
         }
