@@ -124,6 +124,9 @@ def _bind(L):
     L.fr_rendering_layer_forward.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                              ctypes.c_size_t, _vp]
     L.fr_rendering_layer_forward.restype = _i
+    L.fr_rendering_layer_forward_phases.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                                                    ctypes.c_size_t, _vp, _i]
+    L.fr_rendering_layer_forward_phases.restype = _i
     L.fr_render_depth_backward.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     L.fr_render_depth_backward.restype = _i
     L.fr_render_depth_backward_workspace_bytes.argtypes = [_i, _i, _i]
@@ -144,6 +147,12 @@ def _bind(L):
     L.fr_decode_q30_workspace_bytes.restype = ctypes.c_size_t
     L.fr_decode_3dmm_q30.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]
     L.fr_decode_3dmm_q30.restype = _i
+    L.fr_decode_3dmm_q30_lv.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, ctypes.c_size_t, _vp]
+    L.fr_decode_3dmm_q30_lv.restype = _i
+    L.fr_decode_render_forward_q30.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _i, _vp,
+                                               ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
+                                               _vp, _i]
+    L.fr_decode_render_forward_q30.restype = _i
     L.fr_decode_render_vertex_pitch.argtypes = [_i]
     L.fr_decode_render_vertex_pitch.restype = _i
     L.fr_decode_render_vertex_bytes.argtypes = [_i, _i]
@@ -176,6 +185,8 @@ def _bind(L):
     L.fr_debug_render_geom.restype = None
     L.fr_debug_div3_sweep.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]
     L.fr_debug_div3_sweep.restype = _i
+    L.fr_debug_clock_probe.argtypes = [_vp, _i, _i, _vp]
+    L.fr_debug_clock_probe.restype = _i
     return L
 
 
@@ -185,9 +196,11 @@ EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_r
            "fr_render_depth_forward_phases", "fr_debug_render_geom", "fr_debug_div3_sweep",
            "fr_render_depth_backward_workspace_bytes", "fr_render_depth_backward_ws", "fr_set_option", "fr_get_option",
            "fr_decode_q30_image_bytes", "fr_decode_q30_pack", "fr_decode_q30_workspace_bytes", "fr_decode_3dmm_q30",
+           "fr_decode_3dmm_q30_lv", "fr_decode_render_forward_q30",
            "fr_decode_render_vertex_pitch", "fr_decode_render_vertex_bytes", "fr_decode_render_forward",
            "fr_decode_render_pipelined_supported", "fr_decode_render_pipelined",
-           "fr_decode_backward_basis_bytes", "fr_decode_backward_pack_basis", "fr_decode_3dmm_backward_packed"]
+           "fr_decode_backward_basis_bytes", "fr_decode_backward_pack_basis", "fr_decode_3dmm_backward_packed",
+           "fr_debug_clock_probe", "fr_rendering_layer_forward_phases"]
 
 
 def lib():
@@ -218,23 +231,39 @@ def lib():
 DECODE_ARITH_Q30, DECODE_ARITH_F32 = 0, 1
 # This file is loaded under two module names (the package's `3dfacerecon_amd._lib`, and by path from the reference-style
 # flat modules rendering_layer/ops.py, nets/network.py, pipeline.py): process-wide choices live in ONE shared namespace.
-_STATE = sys.modules.setdefault("_fr_hotpath_state", types.SimpleNamespace(decode_arith=None))
+_STATE = sys.modules.setdefault("_fr_hotpath_state", types.SimpleNamespace(decode_arith=None, q30_levels=7))
+_ARITH_ENV = {"q30": 7, "q30l7": 7, "q30l5": 5, "q30l4": 4}
 
 
 def decode_arith():
     """Which written definition of the basis blend the Python callers (FaceRecNet.vertices_transform, DecodeRenderPlan)
-    use: DECODE_ARITH_F32 (default: fr_decode_3dmm, the k-ordered fmaf chain) or DECODE_ARITH_Q30 (fr_decode_3dmm_q30,
-    the frozen exact-fixed-point experiment; its image and workspace are built on first use).  Process-wide; the initial
-    value comes from the environment variable FR_DECODE_ARITH = "f32" | "q30", read once."""
+    use: DECODE_ARITH_F32 (default: fr_decode_3dmm, the k-ordered fmaf chain) or DECODE_ARITH_Q30 (fr_decode_3dmm_q30_lv,
+    the fixed-point blend on the int8 matrix cores with q30_levels() digit-product levels; its image and workspace are built
+    on first use).  Process-wide; the initial value comes from the environment variable FR_DECODE_ARITH = "f32" | "q30"
+    (all seven levels) | "q30l5" | "q30l4", read once."""
     if _STATE.decode_arith is None:
-        _STATE.decode_arith = DECODE_ARITH_Q30 if os.environ.get("FR_DECODE_ARITH") == "q30" else DECODE_ARITH_F32
+        lv = _ARITH_ENV.get(os.environ.get("FR_DECODE_ARITH", ""))
+        _STATE.decode_arith = DECODE_ARITH_Q30 if lv else DECODE_ARITH_F32
+        if lv:
+            _STATE.q30_levels = lv
     return _STATE.decode_arith
 
 
-def set_decode_arith(mode):
+def q30_levels():
+    """Digit-product levels of the Q30 blend (include/fr_hotpath.h): 7 = the exact product, 5, or 4."""
+    decode_arith()
+    return _STATE.q30_levels
+
+
+def set_decode_arith(mode, levels=None):
     if mode not in (DECODE_ARITH_Q30, DECODE_ARITH_F32):
         raise ValueError("decode arithmetic must be DECODE_ARITH_F32 or DECODE_ARITH_Q30")
+    if levels is not None and int(levels) not in (4, 5, 7):
+        raise ValueError("Q30 levels must be 7, 5 or 4")
+    decode_arith()
     _STATE.decode_arith = mode
+    if levels is not None:
+        _STATE.q30_levels = int(levels)
 
 
 def set_option(name, value):

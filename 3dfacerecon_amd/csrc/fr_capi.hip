@@ -19,6 +19,7 @@ const OptDesc kOpts[fr::OPT_COUNT] = {
     {"FR_RENDER_ROWS", 0, nullptr}, {"FR_DECODE_STORE", 0, nullptr},
     {"FR_FUSED_ORDER", 0, nullptr}, {"FR_FUSED_ALONE", 0, nullptr},
     {"FR_BWD_CHUNKS", 256, nullptr}, {"FR_BWD_CB", 0, nullptr}, {"FR_EMIT_ORDER", -1, nullptr},
+    {"FR_Q30_SCHED", 0, nullptr},
 };
 std::atomic<int> g_opt[fr::OPT_COUNT];
 std::once_flag g_opt_once;
@@ -113,9 +114,10 @@ int fr_render_depth_forward_phases(const float* vertex, const float* tri, const 
                                            tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream, phases);
 }
 
-int fr_rendering_layer_forward(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
-                               int nver, int ntri, int H, int W, int tex_batch, float* net_input, float* depth_img,
-                               float* depth, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream) {
+static int rendering_layer_checked(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
+                                   int nver, int ntri, int H, int W, int tex_batch, float* net_input, float* depth_img,
+                                   float* depth, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream, int phases) {
+    if (phases < 1 || phases > 7) return FR_ERR_INVALID_ARG;
     if (B < 0 || nver < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
     if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
     if ((size_t)B * H * W == 0) return FR_OK;
@@ -125,7 +127,22 @@ int fr_rendering_layer_forward(const float* vertex, const float* tri, const floa
     if (ntri == 0 || nver == 0) return FR_ERR_UNSUPPORTED;  // nothing to fuse: use the plain op
     if (ws_bytes < fr_render_depth_workspace_bytes(B, nver, ntri, H, W)) return FR_ERR_WORKSPACE;
     return fr_launch_rendering_layer(vertex, tri, texture, im_gray, B, nver, ntri, H, W, tex_batch, net_input, depth_img,
-                                     depth, tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream);
+                                     depth, tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream, phases);
+}
+
+int fr_rendering_layer_forward(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
+                               int nver, int ntri, int H, int W, int tex_batch, float* net_input, float* depth_img,
+                               float* depth, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream) {
+    return rendering_layer_checked(vertex, tri, texture, im_gray, B, nver, ntri, H, W, tex_batch, net_input, depth_img, depth,
+                                   tri_ind, workspace, ws_bytes, hip_stream, 7);
+}
+
+int fr_rendering_layer_forward_phases(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
+                                      int nver, int ntri, int H, int W, int tex_batch, float* net_input, float* depth_img,
+                                      float* depth, float* tri_ind, void* workspace, size_t ws_bytes, void* hip_stream,
+                                      int phases) {
+    return rendering_layer_checked(vertex, tri, texture, im_gray, B, nver, ntri, H, W, tex_batch, net_input, depth_img, depth,
+                                   tri_ind, workspace, ws_bytes, hip_stream, phases);
 }
 
 static int render_backward_checked(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
@@ -277,17 +294,63 @@ size_t fr_decode_q30_workspace_bytes(int n_shape, int n_exp) {
     return fr_decode_q_workspace_bytes_impl(n_shape, n_exp);
 }
 
-int fr_decode_3dmm_q30(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
-                       int n_exp, float im_size, float* vertex_proj, void* workspace, size_t ws_bytes, void* hip_stream) {
-    if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0) return FR_ERR_INVALID_ARG;
+static int decode_q30_checked(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
+                              int n_exp, float im_size, float* vertex_proj, int pitch, int levels, void* workspace,
+                              size_t ws_bytes, void* hip_stream) {
+    if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0 || !fr_decode_q_levels_ok(levels)) return FR_ERR_INVALID_ARG;
     if (!fr_decode_q_supported(n_shape, n_exp)) return FR_ERR_UNSUPPORTED;
     if ((size_t)B * N == 0) return FR_OK;
-    if (!params || !qimage || !vertex_proj) return FR_ERR_INVALID_ARG;
+    if (!params || !qimage || !vertex_proj || pitch < N) return FR_ERR_INVALID_ARG;
     if (((uintptr_t)qimage & 255) != 0) return FR_ERR_INVALID_ARG;
     if (!workspace || ws_bytes < fr_decode_q_workspace_bytes_impl(n_shape, n_exp) || ((uintptr_t)workspace & 15))
         return FR_ERR_WORKSPACE;
-    return fr_launch_decode_q(params, qimage, R_override, B, N, n_shape, n_exp, im_size, vertex_proj, workspace, ws_bytes,
-                              (hipStream_t)hip_stream);
+    return fr_launch_decode_q(params, qimage, R_override, B, N, n_shape, n_exp, im_size, vertex_proj, pitch, levels, workspace,
+                              ws_bytes, (hipStream_t)hip_stream);
+}
+
+int fr_decode_3dmm_q30(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
+                       int n_exp, float im_size, float* vertex_proj, void* workspace, size_t ws_bytes, void* hip_stream) {
+    return decode_q30_checked(params, qimage, R_override, B, N, n_shape, n_exp, im_size, vertex_proj, N, 7, workspace, ws_bytes,
+                              hip_stream);
+}
+
+int fr_decode_3dmm_q30_lv(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
+                          int n_exp, float im_size, int levels, float* vertex_proj, void* workspace, size_t ws_bytes,
+                          void* hip_stream) {
+    return decode_q30_checked(params, qimage, R_override, B, N, n_shape, n_exp, im_size, vertex_proj, N, levels, workspace,
+                              ws_bytes, hip_stream);
+}
+
+int fr_decode_render_forward_q30(const float* params, const void* qimage, const float* R_override, const float* tri,
+                                 const float* texture, int B, int N, int n_shape, int n_exp, int ntri, int H, int W,
+                                 int tex_batch, float im_size, int levels, float* vertex_handoff, size_t vertex_bytes,
+                                 float* depth, float* tex_img, float* normal, float* tri_ind, void* workspace, size_t ws_bytes,
+                                 void* q_workspace, size_t q_ws_bytes, void* hip_stream, int phases) {
+    if (phases < 1 || phases > 15) return FR_ERR_INVALID_ARG;
+    if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
+    if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
+    if (!fr_decode_q_levels_ok(levels)) return FR_ERR_INVALID_ARG;
+    if (B == 0) return FR_OK;
+    const int pitch = fr_decode_render_vertex_pitch(N);
+    if (N > 0 && (!vertex_handoff || vertex_bytes < fr_decode_render_vertex_bytes(B, N) || ((uintptr_t)vertex_handoff & 127)))
+        return FR_ERR_WORKSPACE;
+    if ((phases & 8) && N > 0) {
+        const int rc = decode_q30_checked(params, qimage, R_override, B, N, n_shape, n_exp, im_size, vertex_handoff, pitch,
+                                          levels, q_workspace, q_ws_bytes, hip_stream);
+        if (rc != FR_OK) return rc;
+    }
+    if (!(phases & 7) || (size_t)H * W == 0) return FR_OK;
+    if (!depth || !tex_img || !normal || !tri_ind) return FR_ERR_INVALID_ARG;
+    if (ntri > 0 && (!tri || (N > 0 && !texture))) return FR_ERR_INVALID_ARG;
+    if (ntri >= (1 << 24)) return FR_ERR_UNSUPPORTED;
+    if (ws_bytes < fr_render_depth_workspace_bytes(B, N, ntri, H, W)) return FR_ERR_WORKSPACE;
+    return fr_launch_render_forward_phases(vertex_handoff, tri, texture, B, N, ntri, H, W, tex_batch, depth, tex_img, normal,
+                                           tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream, phases & 7, pitch);
+}
+
+int fr_debug_clock_probe(unsigned long long* ticks, int blocks, int iters, void* hip_stream) {
+    if (!ticks || blocks < 1 || blocks > 65535 || iters < 1) return FR_ERR_INVALID_ARG;
+    return fr_launch_clock_probe(ticks, blocks, iters, (hipStream_t)hip_stream);
 }
 
 size_t fr_decode_backward_workspace_bytes(int B, int N, int n_shape, int n_exp) {

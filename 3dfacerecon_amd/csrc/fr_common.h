@@ -116,6 +116,8 @@ enum Opt {
     OPT_BWD_CHUNKS,     // FR_BWD_CHUNKS     row chunks (workgroups, partial slabs) of the packed decode-backward GEMM: 256 (default: one workgroup per CU), 1 .. 512
     OPT_BWD_CB,         // FR_BWD_CB         16-coefficient blocks per wave of the fused decode backward: 0 = by batch (default) | 2 | 4
     OPT_EMIT_ORDER,     // FR_EMIT_ORDER     lane order of a segment's triangles: -1 scored per segment (default), 0 identity, 1 even / odd passes
+    OPT_Q30_SCHED,      // FR_Q30_SCHED      Q30 streaming schedule: 0 = 8 waves x whole tiles, 16-deep ring, staging launch (default) |
+                        //                   1 = the same with the parameter digits staged in-kernel | 2 = 16 waves, 32-column halves, 8-deep ring
     OPT_COUNT
 };
 int opt(Opt o);
@@ -131,7 +133,7 @@ int fr_launch_render_forward_phases(const float* vertex, const float* tri, const
                                     long long vpitch = 0);
 int fr_launch_rendering_layer(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
                               int nver, int ntri, int H, int W, int tex_batch, float* net_in, float* depth_img,
-                              float* depth, float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream);
+                              float* depth, float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases = 7);
 int fr_render_pipelined_supported_impl(int B, int ntri, int H, int W);
 int fr_launch_render_pipelined(const float* vertex, const float* vertex_prev, long long vpitch, const float* tri,
                                const float* texture, int B, int nver, int ntri, int H, int W, int tex_batch, float* depth,
@@ -147,12 +149,15 @@ int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc
                          void* packed, hipStream_t stream);
 int fr_launch_decode(const float* params, const void* packed, const float* R_override, int B, int N, int n_shape,
                      int n_exp, float im_size, float* vertex_proj, int pitch, hipStream_t stream);
+int fr_launch_clock_probe(unsigned long long* out, int blocks, int iters, hipStream_t stream);
 size_t fr_packed_q_bytes(int N, int n_shape, int n_exp);
 bool fr_decode_q_supported(int n_shape, int n_exp);
 int fr_launch_pack_q(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
                      void* qimage, hipStream_t stream);
 int fr_launch_decode_q(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
-                       int n_exp, float im_size, float* vertex_proj, void* workspace, size_t ws_bytes, hipStream_t stream);
+                       int n_exp, float im_size, float* vertex_proj, int pitch, int levels, void* workspace, size_t ws_bytes,
+                       hipStream_t stream);
+bool fr_decode_q_levels_ok(int levels);
 size_t fr_decode_q_workspace_bytes_impl(int n_shape, int n_exp);
 int fr_device_cu_count();
 size_t fr_decode_backward_workspace_impl(int N, int ns, int ne);

@@ -495,6 +495,31 @@ void decode_ring_kernel(DecodeArgs a) {
 #undef FR_REQ
 }
 
+// Measurement hook (bench.py `clock_GHz_held`): every wave of a 16-wave workgroup per CU issues `iters` rounds of six independent
+// v_mfma_f32_16x16x4_f32 -- the decode's matrix instruction at the decode's occupancy -- and lane 0 of each workgroup records how
+// many shader-clock ticks (s_memtime) and 100 MHz ticks (s_memrealtime) its loop took: their quotient is the clock the chip
+// holds under that load (MI355X_MICROARCH.md, DVFS give-back (6)).  The stamps go to a buffer of their own.
+__global__ __launch_bounds__(1024) void clock_probe_kernel(unsigned long long* __restrict__ out, int iters, float a0, float b0) {
+    f32x4 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float a = a0 + (float)threadIdx.x, b = b0 + 0.5f * (float)threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    float sink = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) sink += acc[i][0] + acc[i][3];
+    asm volatile("" ::"v"(sink));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = t1 - t0;
+        out[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
 }  // namespace fr
 
 // The packed buffer holds the f32 A-fragment image of this file (the Q30 digit image of fr_decode_q.hip is a separate,
@@ -516,6 +541,11 @@ int fr_launch_pack_basis(const float* mu, const float* pc_shape, const float* pc
     float* mu_p = reinterpret_cast<float*>(A + tiles * G * 3 * 64);
     hipLaunchKernelGGL(pack_basis_kernel, dim3(2048), dim3(256), 0, stream, mu, pc_shape, pc_exp, N, n_shape, n_exp, A,
                        mu_p);
+    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
+}
+
+int fr_launch_clock_probe(unsigned long long* out, int blocks, int iters, hipStream_t stream) {
+    hipLaunchKernelGGL(fr::clock_probe_kernel, dim3(blocks), dim3(1024), 0, stream, out, iters, 1.0f, 2.0f);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 

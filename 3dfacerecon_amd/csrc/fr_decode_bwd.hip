@@ -683,9 +683,13 @@ size_t fr_decode_backward_workspace_impl(int N, int ns, int ne) {
 
 // the packed path serves bases of at most 16 coefficient blocks (see bwd_fused_kernel)
 static bool bwd_packed_supported(int ns, int ne) { return ns + ne > 0 && (ns + 15) / 16 + (ne + 15) / 16 <= 16; }
+// ... and meshes of at least one whole 16-vertex tile: the fused kernel clamps a tile's origin to max(N - 16, 0) and always loads
+// sixteen floats per row, which for N < 16 would run past the row (and, for the last batch's z row, past the tensor).  Smaller
+// meshes take the reference-layout entry point (fr_decode_backward_basis_bytes answers 0 for them).
+static bool bwd_packed_mesh_ok(int N) { return N >= 16; }
 
 size_t fr_decode_backward_basis_bytes_impl(int N, int ns, int ne) {
-    if (N <= 0 || !bwd_packed_supported(ns, ne)) return 0;
+    if (N <= 0 || !bwd_packed_supported(ns, ne) || !bwd_packed_mesh_ok(N)) return 0;
     return fr::bwd_geom(N, ns, ne).at_bytes;
 }
 
@@ -693,7 +697,7 @@ int fr_launch_decode_backward_pack(const float* pc_shape, const float* pc_exp, i
                                    hipStream_t stream) {
     using namespace fr;
     if (N <= 0 || ns + ne <= 0) return FR_OK;
-    if (!bwd_packed_supported(ns, ne)) return FR_ERR_UNSUPPORTED;
+    if (!bwd_packed_supported(ns, ne) || !bwd_packed_mesh_ok(N)) return FR_ERR_UNSUPPORTED;
     BwdGeom g = bwd_geom(N, ns, ne);
     hipLaunchKernelGGL(bwd_pack_kernel, dim3(2048), dim3(256), 0, stream, pc_shape, pc_exp, N, ns, ne, g.sbs, g.sbt,
                        (long long)g.ngroups, reinterpret_cast<float4*>(packed_t));
@@ -711,7 +715,7 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
                                                                                                              : FR_ERR_LAUNCH;
     BwdGeom g = bwd_geom(N, ns, ne);
     const bool packed = packed_t != nullptr;
-    if (packed && !bwd_packed_supported(ns, ne)) return FR_ERR_UNSUPPORTED;
+    if (packed && (!bwd_packed_supported(ns, ne) || !bwd_packed_mesh_ok(N))) return FR_ERR_UNSUPPORTED;
     const int waves = packed ? g.waves_p : bw_waves(ns, ne);
     if (waves > BW_MAXWAVES) return FR_ERR_UNSUPPORTED;  // > 512 coefficient slots
     BwdArgs a;

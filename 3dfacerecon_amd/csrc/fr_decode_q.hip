@@ -284,28 +284,135 @@ __device__ __forceinline__ void q_copy_stage(const char* __restrict__ stage, cha
     __syncthreads();
 }
 
-// One coordinate's seven level sums -> fl32(mu + I 2^(re + be - 60)) for this lane's 4 rows x NBW columns.
-template <int NBW>
-__device__ __forceinline__ void q_finish(const i32x4 (&acc)[7][NBW], const float (&mu4)[4], const int (&e4)[4],
+// the model's basis shape (199 + 29 coefficients): 15 live 16-k groups, 4 k-steps of 64, 3 groups in the last one, 48 fragments
+constexpr int QR_KB = 15, QR_S = 4, QR_NGL = 3, QR_F = 48;
+constexpr size_t QR_CB = (size_t)1024 * QR_KB, QR_TB = 3 * QR_CB + 256;
+
+// The same image built INSIDE the decode kernel, by every workgroup for itself, for the model's shape (S = 4 k-steps): the
+// staging launch costs the stream 5 us of kernel + a launch gap per pass, the in-kernel form ~2 us of each CU's time under
+// the latency of the ring's first requests.  Integer / fp32 forms of the specification's steps, each exact:
+//   * x 2^s is a power-of-two scaling of an fp32 number to at most 2^30: exact in fp32 (v_ldexp_f32; anything that would
+//     underflow rounds to 0 under rint either way), so rint(ldexp((double)x, s)) == (int)rndne(ldexp(x, s));
+//   * the four balanced base-256 digits of q are the bytes of (q + 0x808080) ^ 0x808080 (adding 128 to each of the three low
+//     bytes with carry is the digit recurrence; the xor turns the biased bytes into two's complement);
+//   * four consecutive k of one column are one dword per digit fragment: a 4 x 4 byte transpose in eight v_perm_b32.
+// Lane = (column & 15, k-quad & 3): a wave's ds_write_b32 then covers 64 consecutive dwords of a fragment (no bank conflicts),
+// and its parameter loads are sixteen 64-byte row pieces.  `scratch`: 3 KiB of LDS for the pose's sin / cos (float64).
+template <int DEC_BLOCK>
+__device__ __forceinline__ void q_stage_lds(const DecodeQArgs& a, char* lds, double* scratch, int tid, int nbatch) {
+    constexpr int NW = DEC_BLOCK / 64;
+    constexpr int ITEMS = 64 / NW;            // (column block, k-quad group) pairs per wave: 4 x 16 in all
+    static_assert(64 % NW == 0, "waves per workgroup");
+    char* Bimg = lds;
+    float* Mt = reinterpret_cast<float*>(Bimg + (size_t)QR_S * 16384);
+    int* be_s = reinterpret_cast<int*>(Mt + MAXB * 12);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int b_lo = lane & 15, u_lo = lane >> 4;
+    const int K = a.qs.K;
+    const int nd = FR_N_POSE + a.d.ns + a.d.ne;
+    if (tid < MAXB) be_s[tid] = INT_MIN;
+    float x[ITEMS][4];
+    int cek[ITEMS][4];
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const int c = wave * ITEMS + it, nb = c >> 4, u = 4 * (c & 15) + u_lo, b = 16 * nb + b_lo;
+        const bool live = b < nbatch;
+        const float* pr = a.d.params + (size_t)(a.d.b0 + (live ? b : 0)) * nd + FR_N_POSE;
+        const int4 c4 = *reinterpret_cast<const int4*>(a.ce + 4 * u);
+        cek[it][0] = c4.x; cek[it][1] = c4.y; cek[it][2] = c4.z; cek[it][3] = c4.w;
+        // unconditional, clamped loads, all issued before any is consumed (a load under its own `k < K` predicate becomes a
+        // branch with a vmcnt(0) of its own: thirty-two dependent round trips per thread, measured +6 us per launch)
+#pragma unroll
+        for (int t = 0; t < 4; t++) x[it][t] = pr[min(4 * u + t, K > 0 ? K - 1 : 0)];
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) asm volatile("" : "+v"(x[it][t]));
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const int c = wave * ITEMS + it, u = 4 * (c & 15) + u_lo, b = 16 * (c >> 4) + b_lo;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (!(b < nbatch && 4 * u + t < K)) x[it][t] = 0.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // be_s initialised
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const int c = wave * ITEMS + it, b = 16 * (c >> 4) + b_lo;
+        int e = INT_MIN;
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float v = x[it][t];
+            if (!isfinite(v)) bad = true;
+            else if (v != 0.f) e = max(e, __builtin_amdgcn_frexp_expf(v) + cek[it][t]);
+        }
+        if (bad) atomicMax(&be_s[b], Q_BE_BAD);
+        else if (e != INT_MIN) atomicMax(&be_s[b], e);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const int c = wave * ITEMS + it, nb = c >> 4, uh = c & 15, b = 16 * nb + b_lo;
+        int be = be_s[b];
+        if (be == INT_MIN) be = 0;
+        unsigned W[4] = {0u, 0u, 0u, 0u};
+        if (be != Q_BE_BAD) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int q = (int)__builtin_rintf(__builtin_ldexpf(x[it][t], cek[it][t] + 30 - be));
+                W[t] = ((unsigned)q + 0x808080u) ^ 0x808080u;
+            }
+        }
+        const unsigned h01 = __builtin_amdgcn_perm(W[1], W[0], 0x06020703u), l01 = __builtin_amdgcn_perm(W[1], W[0], 0x04000501u);
+        const unsigned h23 = __builtin_amdgcn_perm(W[3], W[2], 0x06020703u), l23 = __builtin_amdgcn_perm(W[3], W[2], 0x04000501u);
+        unsigned o[4];
+        o[0] = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
+        o[1] = __builtin_amdgcn_perm(h23, h01, 0x07060302u);
+        o[2] = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
+        o[3] = __builtin_amdgcn_perm(l23, l01, 0x07060302u);
+        const int sidx = uh >> 2, g = uh & 3;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<unsigned*>(Bimg + ((size_t)((sidx * 4 + j) * 4 + nb) * 64 + g * 16 + b_lo) * 16 + 4 * u_lo) = o[j];
+    }
+    if (tid < MAXB && tid >= nbatch) be_s[tid] = 0;
+    else if (tid < MAXB && be_s[tid] == INT_MIN) be_s[tid] = 0;
+    pose_prologue<MAXB>(a.d, Mt, scratch, tid, nd, nbatch);   // two barriers: publishes the image, be_s and Mt
+}
+
+// One coordinate's LV level sums -> fl32(mu + h 2^(be - e_r - 60 + 8 (7 - LV))) for this lane's 4 rows x NBW columns, h the
+// written chain h = fl64(h * 256 + L_s).  Two steps are taken in cheaper, bit-identical forms: the leading digits of the
+// 31-bit operands are at most 64 in magnitude, so with K <= 512 coefficients |L_0| <= 2^21 and |L_1| <= 2^23 and
+// L_0 * 256 + L_1 is exact in int32 (one integer instruction instead of two conversions and a float64 multiply-add); and
+// h * 2^e is exact (a power of two, far from the exponent range's ends), so fma(h, 2^e, mu) == mu + h * 2^e to the bit.
+template <int LV, int NBW>
+__device__ __forceinline__ void q_finish(const i32x4 (&acc)[LV][NBW], const float (&mu4)[4], const int (&e4)[4],
                                          const int (&be)[NBW], f32x4 (&out)[NBW]) {
 #pragma unroll
     for (int nb = 0; nb < NBW; nb++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            double h = (double)acc[0][nb][r];
+            double h;
+            if constexpr (LV >= 2) {
+                h = (double)(acc[0][nb][r] * 256 + acc[1][nb][r]);
 #pragma unroll
-            for (int s = 1; s < 7; s++) h = __builtin_fma(h, 256.0, (double)acc[s][nb][r]);
+                for (int s = 2; s < LV; s++) h = __builtin_fma(h, 256.0, (double)acc[s][nb][r]);
+            } else {
+                h = (double)acc[0][nb][r];
+            }
             const bool bad = e4[r] == 1023 || be[nb] == Q_BE_BAD;
-            const int e = bad ? 0 : be[nb] - e4[r] - 60;
+            const int e = bad ? 0 : be[nb] - e4[r] - 60 + 8 * (7 - LV);
             const double sc = __longlong_as_double((long long)(1023 + e) << 52);
-            const double d = (double)mu4[r] + h * sc;
+            const double d = __builtin_fma(h, sc, (double)mu4[r]);
             out[nb][r] = bad ? __uint_as_float(0x7FC00000u) : (float)d;
         }
     }
 }
 
 // Generic kernel (any basis shape with ns + ne <= 512): one wave per 16-vertex tile, NBW column blocks, plain loads.
-template <int NBW, int DEC_WAVES>
+template <int NBW, int DEC_WAVES, int LV>
 __global__ __launch_bounds__(DEC_WAVES * 64) void decode_q_kernel(DecodeQArgs a) {
     constexpr int DEC_BLOCK = DEC_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char qsmem[];
@@ -332,9 +439,9 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_q_kernel(DecodeQArgs a)
         f32x4 v[3][NBW];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            i32x4 acc[7][NBW];
+            i32x4 acc[LV][NBW];
 #pragma unroll
-            for (int s = 0; s < 7; s++)
+            for (int s = 0; s < LV; s++)
 #pragma unroll
                 for (int nb = 0; nb < NBW; nb++) acc[s][nb] = (i32x4){0, 0, 0, 0};
             for (int sidx = 0; sidx < qs.S; sidx++) {
@@ -345,15 +452,18 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_q_kernel(DecodeQArgs a)
                     af[i] = *reinterpret_cast<const i32x4*>(tb + q_frag_off(qs, c, sidx, i) + (size_t)lane * 16);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
+                    if (j >= LV) continue;   // (no kept product uses this parameter digit)
                     i32x4 bf[NBW];
 #pragma unroll
                     for (int nb = 0; nb < NBW; nb++)
                         bf[nb] = *reinterpret_cast<const i32x4*>(Bimg + ((size_t)((s * 4 + j) * 4 + a.cb0 + nb) * 64 + lane) * 16);
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
+                    for (int i = 0; i < 4; i++) {
+                        if (i + j >= LV) continue;   // kept products: i + j < LV
 #pragma unroll
                         for (int nb = 0; nb < NBW; nb++)
                             acc[i + j][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[nb], acc[i + j][nb], 0, 0, 0);
+                    }
                 }
             }
             float mu4[4];
@@ -363,7 +473,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decode_q_kernel(DecodeQArgs a)
                 mu4[r] = __uint_as_float(c == 0 ? pay[r].x : c == 1 ? pay[r].y : pay[r].z);
                 e4[r] = (int)((pay[r].w >> (10 * c)) & 1023u);
             }
-            q_finish<NBW>(acc, mu4, e4, be, v[c]);
+            q_finish<LV, NBW>(acc, mu4, e4, be, v[c]);
         }
         decode_store<NBW>(a.d, v[0], v[1], v[2], Mt, tile, a.cb0 / NBW, lane, nbatch, a.d.N);
     }
@@ -388,8 +498,6 @@ __device__ __forceinline__ void q_ring_wait4(i32x4& a0, i32x4& a1, i32x4& a2, i3
     else if constexpr (R == 12) asm volatile("s_waitcnt vmcnt(8)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
     else asm volatile("s_waitcnt vmcnt(12)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
 }
-constexpr int QR_KB = 15, QR_S = 4, QR_NGL = 3, QR_F = 48;
-constexpr size_t QR_CB = (size_t)1024 * QR_KB, QR_TB = 3 * QR_CB + 256;
 __host__ __device__ constexpr size_t qr_off(int f) {
     return (size_t)(f / 16) * QR_CB +
            (((f % 16) / 4) == 0 ? (size_t)(f % 4) * 256 * QR_NGL
@@ -397,12 +505,18 @@ __host__ __device__ constexpr size_t qr_off(int f) {
            (f ? 256 : 0);
 }
 
-template <int R, int NBW, int DEC_WAVES, int WPE, bool NT>
+// LV: digit-product levels kept (7 = all sixteen products; 5 = thirteen; 4 = ten -- the spec's LV).
+// H2: waves that share a tile (1: a wave owns all of a tile's NBW column blocks; 2: NBW = 2 and the tile's two 32-column halves
+// go to neighbouring waves, which stream the same fragments at the same time -- the second request is an L1 / L2 hit -- so that
+// the accumulators of one wave (LV x NBW x 4 registers) leave room for four waves per SIMD).
+// STAGE: the parameter image is built in-kernel (q_stage_lds) instead of copied from the staging launch's buffer.
+template <int R, int NBW, int DEC_WAVES, int WPE, bool NT, int LV, int H2, bool STAGE>
 __global__ __launch_bounds__(DEC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void decode_q_ring_kernel(DecodeQArgs a) {
     constexpr int DEC_BLOCK = DEC_WAVES * 64;
     constexpr int F = QR_F;
     static_assert(F % R == 0 && R % 4 == 0, "the ring must close on an item boundary, in whole groups");
+    static_assert(NBW * H2 <= 4 && DEC_WAVES % H2 == 0, "a pass holds four 16-column blocks");
     extern __shared__ __attribute__((aligned(16))) char qsmem[];
     char* Bimg = qsmem;                                                        // 4 k-steps x 16 KiB
     float* Mt = reinterpret_cast<float*>(Bimg + (size_t)QR_S * 16384);          // [64][12]
@@ -410,13 +524,13 @@ void decode_q_ring_kernel(DecodeQArgs a) {
     uint4* pay_s = reinterpret_cast<uint4*>(be_s + MAXB);                       // [DEC_WAVES][16]
     f32x4* park_s = reinterpret_cast<f32x4*>(pay_s + DEC_WAVES * 16);           // [DEC_WAVES][2][NBW][64]
     const int tid = threadIdx.x;
-    const int nd = FR_N_POSE + a.d.ns + a.d.ne;
     const int nbatch = min(a.d.B - a.d.b0, MAXB);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles = tiles_of(a.d.N);
     const int N = a.d.N;
-    const TileWalk tw = tile_walk(wave, DEC_WAVES, (int)blockIdx.x, (int)gridDim.x);
+    const int slot = wave / H2, hf = wave - slot * H2;
+    const TileWalk tw = tile_walk(slot, DEC_WAVES / H2, (int)blockIdx.x, (int)gridDim.x);
     const int tile0 = tw.first, tstride = tw.stride;
     const unsigned voffA = (unsigned)lane * 16u;
     const char* Tb = a.tiles;
@@ -427,12 +541,16 @@ void decode_q_ring_kernel(DecodeQArgs a) {
         const char* sb_ = Tb + (size_t)(t_) * QR_TB + qr_off(f_);                \
         FRQ_LD(ring[slot_], sb_, voffA);                                         \
     }
+    // (STAGE: the parameter loads must not queue behind the ring's first requests -- vmcnt returns in order, and the priming
+    // burst of every CU at once is 32 MB of cold HBM reads -- so the image is built first and the ring primed after it;
+    // primed first, with the staging behind it, the kernel measured the same)
+    if constexpr (STAGE) q_stage_lds<DEC_BLOCK>(a, qsmem, reinterpret_cast<double*>(park_s), tid, nbatch);
     {
         const int t0c = tile0 < tiles ? tile0 : 0;
 #pragma unroll
         for (int f = 0; f < R; f++) FRQ_REQ(f, f, t0c)
     }
-    q_copy_stage<DEC_BLOCK>(a.stage, qsmem, QR_S, tid);
+    if constexpr (!STAGE) q_copy_stage<DEC_BLOCK>(a.stage, qsmem, QR_S, tid);
     if (tile0 >= tiles) {
 #pragma unroll
         for (int f = 0; f < R; f++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[f]));
@@ -440,22 +558,22 @@ void decode_q_ring_kernel(DecodeQArgs a) {
     }
     int be[NBW];
 #pragma unroll
-    for (int nb = 0; nb < NBW; nb++) be[nb] = be_s[16 * nb + (lane & 15)];
+    for (int nb = 0; nb < NBW; nb++) be[nb] = be_s[16 * (hf * NBW + nb) + (lane & 15)];
     uint4* pay_w = pay_s + wave * 16;
     f32x4* park_w = park_s + (size_t)wave * 2 * NBW * 64 + lane;
-    const char* Bl = Bimg + (size_t)lane * 16;
+    const char* Bl = Bimg + (size_t)(hf * NBW) * 1024 + (size_t)lane * 16;
 
     for (int ct = tile0; ct < tiles; ct += tstride) {
         int nt = ct + tstride;
         if (nt >= tiles) nt = tile0;   // past the end: harmless re-request of a valid address, never consumed
-        i32x4 acc[7][NBW];
+        i32x4 acc[LV][NBW];
 #pragma unroll
         for (int g = 0; g < F / 4; g++) {
             const int f0 = 4 * g, c = g / 4, sidx = g % 4;
             const int s = sidx == 0 ? QR_S - 1 : sidx - 1;
             if (sidx == 0) {
 #pragma unroll
-                for (int l = 0; l < 7; l++)
+                for (int l = 0; l < LV; l++)
 #pragma unroll
                     for (int nb = 0; nb < NBW; nb++) acc[l][nb] = (i32x4){0, 0, 0, 0};
             }
@@ -468,15 +586,18 @@ void decode_q_ring_kernel(DecodeQArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                if (j >= LV) continue;   // (no kept product uses this parameter digit)
                 i32x4 bf[NBW];
 #pragma unroll
                 for (int nb = 0; nb < NBW; nb++)
                     bf[nb] = *reinterpret_cast<const i32x4*>(Bl + (size_t)((s * 4 + j) * 4 + nb) * 1024);
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int i = 0; i < 4; i++) {
+                    if (i + j >= LV) continue;   // kept products: i + j < LV
 #pragma unroll
                     for (int nb = 0; nb < NBW; nb++)
                         acc[i + j][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[(f0 + i) % R], bf[nb], acc[i + j][nb], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -493,7 +614,7 @@ void decode_q_ring_kernel(DecodeQArgs a) {
                     e4[r] = (int)((row.w >> (10 * c)) & 1023u);
                 }
                 f32x4 vz[NBW];
-                q_finish<NBW>(acc, mu4, e4, be, vz);
+                q_finish<LV, NBW>(acc, mu4, e4, be, vz);
                 if (c < 2) {
 #pragma unroll
                     for (int nb = 0; nb < NBW; nb++) park_w[(size_t)(c * NBW + nb) * 64] = vz[nb];
@@ -504,7 +625,7 @@ void decode_q_ring_kernel(DecodeQArgs a) {
                         vx[nb] = park_w[(size_t)nb * 64];
                         vy[nb] = park_w[(size_t)(NBW + nb) * 64];
                     }
-                    decode_store<NBW>(a.d, vx, vy, vz, Mt, ct, 0, lane, nbatch, N);
+                    decode_store<NBW>(a.d, vx, vy, vz, Mt, ct, hf, lane, nbatch, N);
                 }
             }
         }
@@ -552,32 +673,73 @@ int fr_launch_pack_q(const float* mu, const float* pc_shape, const float* pc_exp
 
 bool fr_decode_q_supported(int n_shape, int n_exp) { return n_shape + n_exp <= 512; }
 
-template <int NBW>
+template <int NBW, int LV>
 static int launch_q_generic(const fr::DecodeQArgs& a, size_t lds, int cus, hipStream_t stream) {
     static fr_lds_flags_t lds_ok[64];
-    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_q_kernel<NBW, 8>), lds_ok) != hipSuccess)
+    if (fr_allow_full_lds(reinterpret_cast<const void*>(&fr::decode_q_kernel<NBW, 8, LV>), lds_ok) != hipSuccess)
         return FR_ERR_LAUNCH;
     const int tiles = fr::tiles_of(a.d.N);
     const int grid = (int)min((long long)cus, (long long)(tiles + 7) / 8);
-    hipLaunchKernelGGL((fr::decode_q_kernel<NBW, 8>), dim3(grid), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((fr::decode_q_kernel<NBW, 8, LV>), dim3(grid), dim3(512), lds, stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
-template <int R, int NBW, int WAVES, bool NT>
+template <int R, int NBW, int WAVES, int WPE, int LV, int H2, bool STAGE = false>
 static int launch_q_ring(const fr::DecodeQArgs& a, int cus, hipStream_t stream) {
     static fr_lds_flags_t lds_ok[64];
-    const void* k = reinterpret_cast<const void*>(&fr::decode_q_ring_kernel<R, NBW, WAVES, WAVES / 4, NT>);
+    const void* k = reinterpret_cast<const void*>(&fr::decode_q_ring_kernel<R, NBW, WAVES, WPE, true, LV, H2, STAGE>);
     if (fr_allow_full_lds(k, lds_ok) != hipSuccess) return FR_ERR_LAUNCH;
     const size_t lds = fr::q_stage_bytes(fr::QR_S) + (size_t)WAVES * 256 + (size_t)WAVES * 2 * NBW * 1024;
     const int tiles = fr::tiles_of(a.d.N);
-    const int grid = (int)min((long long)cus, (long long)(tiles + WAVES - 1) / WAVES);
-    hipLaunchKernelGGL((fr::decode_q_ring_kernel<R, NBW, WAVES, WAVES / 4, NT>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    const int slots = WAVES / H2;
+    const int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
+    static_assert(!STAGE || (size_t)WAVES * 2 * NBW * 1024 >= 3072, "the pose scratch lives in the parking area");
+    hipLaunchKernelGGL((fr::decode_q_ring_kernel<R, NBW, WAVES, WPE, true, LV, H2, STAGE>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
+// One pass (<= 64 columns, nbt live 16-column blocks) of the model's basis shape through the streaming schedule.
+//   sched 0 (default): 8 waves per CU, a wave owns a tile's nbt column blocks (every basis byte is requested once on the chip),
+//                      16-deep fragment ring, behind the staging launch (q_stage_kernel)
+//   sched 1: the same kernel with the parameter image built in-kernel (q_stage_lds: no staging launch).  Measured equal one
+//            batch at a time and 2.5 us slower with two batches in flight, where the staging launch hides behind the other
+//            stream's kernels (profiles/round5_probes/r5b)
+//   sched 2: 16 waves per CU at <= 128 registers (12 at <= 168 with all seven levels), 8-deep ring, a full pass cut into two
+//            32-column halves per tile taken by neighbouring waves (the f32 kernel's arrangement; measured 2-7 us slower: the
+//            partner's request of a non-temporal fragment misses L2 too often)
+template <int LV>
+static int launch_q_pass(const fr::DecodeQArgs& a, int nbt, int sched, int cus, hipStream_t stream) {
+    if (sched == 1)
+        return nbt == 1 ? launch_q_ring<16, 1, 8, 2, LV, 1, true>(a, cus, stream)
+               : nbt == 2 ? launch_q_ring<16, 2, 8, 2, LV, 1, true>(a, cus, stream)
+                          : launch_q_ring<16, 4, 8, 2, LV, 1, true>(a, cus, stream);
+    if (sched != 2 || nbt <= 2)
+        return nbt == 1 ? launch_q_ring<16, 1, 8, 2, LV, 1>(a, cus, stream)
+               : nbt == 2 ? launch_q_ring<16, 2, 8, 2, LV, 1>(a, cus, stream)
+                          : launch_q_ring<16, 4, 8, 2, LV, 1>(a, cus, stream);
+    // (all seven levels: 56 accumulators + the ring do not fit 128 registers -- twelve waves at <= 168)
+    if constexpr (LV == 7) return launch_q_ring<8, 2, 12, 3, LV, 2>(a, cus, stream);
+    else return launch_q_ring<8, 2, 16, 4, LV, 2>(a, cus, stream);
+}
+template <int LV>
+static int launch_q_generic_pass(fr::DecodeQArgs& a, int nbt, size_t lds, int cus, hipStream_t stream) {
+    // (three or four column blocks: two passes of two -- one wave holding four blocks' accumulators spills)
+    int rc = nbt == 1 ? launch_q_generic<1, LV>(a, lds, cus, stream) : launch_q_generic<2, LV>(a, lds, cus, stream);
+    if (rc == FR_OK && nbt > 2) {
+        a.cb0 = 2;
+        rc = launch_q_generic<2, LV>(a, lds, cus, stream);
+        a.cb0 = 0;
+    }
+    return rc;
+}
+
+bool fr_decode_q_levels_ok(int levels) { return levels == 7 || levels == 5 || levels == 4; }
+
 int fr_launch_decode_q(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
-                       int n_exp, float im_size, float* vertex_proj, void* workspace, size_t ws_bytes, hipStream_t stream) {
+                       int n_exp, float im_size, float* vertex_proj, int pitch, int levels, void* workspace, size_t ws_bytes,
+                       hipStream_t stream) {
     using namespace fr;
+    if (!fr_decode_q_levels_ok(levels)) return FR_ERR_INVALID_ARG;
     if (B == 0 || N == 0) return FR_OK;
     DecodeQArgs a;
     a.qs = q_shape(n_shape, n_exp);
@@ -591,7 +753,7 @@ int fr_launch_decode_q(const float* params, const void* qimage, const float* R_o
     a.d.B = B; a.d.N = N; a.d.ns = n_shape; a.d.ne = n_exp;
     a.d.halves = 1;
     a.d.im_size = im_size;
-    a.d.pitch = N;
+    a.d.pitch = pitch;
     const size_t lds = q_stage_bytes(a.qs.S);
     if (lds > 160 * 1024) return FR_ERR_UNSUPPORTED;
     if (!workspace || ws_bytes < lds || ((uintptr_t)workspace & 15)) return FR_ERR_WORKSPACE;
@@ -600,24 +762,21 @@ int fr_launch_decode_q(const float* params, const void* qimage, const float* R_o
     a.cb0 = 0;
     const int cus = fr_device_cu_count();
     const bool loop_env = opt(OPT_DECODE_IMPL) == 1;
+    const int sched = opt(OPT_Q30_SCHED);
     for (int b0 = 0; b0 < B; b0 += MAXB) {
         a.d.b0 = b0;
-        hipLaunchKernelGGL(q_stage_kernel, dim3(MAXB), dim3(128), 0, stream, a, stage);
         const int nbt = (min(B - b0, MAXB) + 15) / 16;
-        if (!loop_env && a.qs.KB == QR_KB) {   // the model's basis shape: streaming schedule
-            int rc = nbt == 1 ? launch_q_ring<16, 1, 8, true>(a, cus, stream)
-                     : nbt == 2 ? launch_q_ring<16, 2, 8, true>(a, cus, stream)
-                                : launch_q_ring<16, 4, 8, true>(a, cus, stream);
-            if (rc != FR_OK) return rc;
-            continue;
-        }
-        // (three or four column blocks: two passes of two -- one wave holding four blocks' 112 accumulators spills)
-        int rc = nbt == 1 ? launch_q_generic<1>(a, lds, cus, stream) : launch_q_generic<2>(a, lds, cus, stream);
-        if (rc == FR_OK && nbt > 2) {
-            a.cb0 = 2;
-            rc = launch_q_generic<2>(a, lds, cus, stream);
-            a.cb0 = 0;
-        }
+        const bool ring = !loop_env && a.qs.KB == QR_KB;
+        if (!(ring && sched == 1)) hipLaunchKernelGGL(q_stage_kernel, dim3(MAXB), dim3(128), 0, stream, a, stage);
+        int rc;
+        if (ring)   // the model's basis shape: streaming schedule
+            rc = levels == 7 ? launch_q_pass<7>(a, nbt, sched, cus, stream)
+                 : levels == 5 ? launch_q_pass<5>(a, nbt, sched, cus, stream)
+                               : launch_q_pass<4>(a, nbt, sched, cus, stream);
+        else
+            rc = levels == 7 ? launch_q_generic_pass<7>(a, nbt, lds, cus, stream)
+                 : levels == 5 ? launch_q_generic_pass<5>(a, nbt, lds, cus, stream)
+                               : launch_q_generic_pass<4>(a, nbt, lds, cus, stream);
         if (rc != FR_OK) return rc;
     }
     return FR_OK;

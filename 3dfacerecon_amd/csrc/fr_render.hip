@@ -1771,9 +1771,9 @@ int fr_launch_render_forward_phases(const float* vertex, const float* tri, const
 
 int fr_launch_rendering_layer(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
                               int nver, int ntri, int H, int W, int tex_batch, float* net_in, float* depth_img,
-                              float* depth, float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream) {
+                              float* depth, float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases) {
     return launch_render_impl(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, nullptr, nullptr, tri_ind, im_gray,
-                              net_in, depth_img, workspace, ws_bytes, stream);
+                              net_in, depth_img, workspace, ws_bytes, stream, phases);
 }
 
 // Argument block + geometry of one forward call (everything the kernels read); *binned = the binned rasteriser serves it.

@@ -14,6 +14,10 @@ The render loop between the iterations is the MI355X hot path: FaceRecNet.vertic
 FaceRecNet.coarse_net_input (fr_rendering_layer_forward), both differentiable.
 """
 import os
+import warnings
+
+import torch
+import torch.nn as nn
 
 # MIOpen 3.5.0 on gfx950: while PyTorch's default (non-immediate) convolution path benchmarks the applicable solvers the
 # first time it sees a shape, the assembly implicit-GEMM backward-data kernel `igemm_bwd_gtcx35_nhwc_fp32_bx0_ex1_bt256x64x4_...`
@@ -21,12 +25,26 @@ import os
 # shapes.  Inside torch's caching allocator the overrun usually lands in mapped memory and goes unnoticed; when the buffer
 # ends on the last page of a segment the process dies with "Memory access fault by GPU" (found with serialized launches +
 # AMD_LOG_LEVEL=3 on a fresh box with an empty MIOpen user database: the faulting launch is that kernel, inside
-# miopenFindConvolutionBackwardDataAlgorithm).  The solver is switched off for processes that build these nets -- MIOpen
-# reads the variable when it first checks the solver's applicability, i.e. after this import; an explicit setting wins.
-os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
+# miopenFindConvolutionBackwardDataAlgorithm; profiles/round4_probes/r4r).
+# The cure is a PROCESS setting (it switches the solver off for every convolution of the host application), so this library
+# module does not apply it behind the caller's back: the entry points (examples/coarse_loop.py, tests/conftest.py) call
+# apply_miopen_workaround() before the first convolution runs -- MIOpen reads the variable when it first checks the solver's
+# applicability -- INTEGRATION.md lists it as a launch requirement, and building a trainable net without it warns.
+MIOPEN_WORKAROUND = ("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
 
-import torch  # noqa: E402
-import torch.nn as nn  # noqa: E402
+
+def apply_miopen_workaround():
+    """For a program's entry point: switch the faulting MIOpen solver off unless the environment already says something
+    explicit.  Returns the value in effect."""
+    return os.environ.setdefault(*MIOPEN_WORKAROUND)
+
+
+def _warn_if_exposed():
+    name, want = MIOPEN_WORKAROUND
+    if os.environ.get(name) != want:
+        warnings.warn("%s is not %s: MIOpen's ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC solver can fault in the backward of these "
+                      "nets on gfx950 (INTEGRATION.md, launch requirements); call nets.coarse_net.apply_miopen_workaround() before "
+                      "the first convolution runs" % (name, want), RuntimeWarning, stacklevel=3)
 
 
 def _conv_bn_relu(cin, cout, k, stride=1, act=True):
@@ -94,6 +112,7 @@ class CoarseNet(nn.Module):
 
     def __init__(self, face_net, nIter=4):
         super().__init__()
+        _warn_if_exposed()
         self.face_net = face_net        # nets.network.FaceRecNet (holds the 3DMM constants on the GPU)
         self.iters = nn.ModuleList([CoarseNetIter(face_net.ndim) for _ in range(nIter)])
 
@@ -122,6 +141,7 @@ class FineNet(nn.Module):
 
     def __init__(self):
         super().__init__()
+        _warn_if_exposed()
         self.conv1 = nn.Sequential(_conv_bn_relu(2, 64, 3), _conv_bn_relu(64, 64, 3))
         self.conv2 = nn.Sequential(_conv_bn_relu(64, 128, 3), _conv_bn_relu(128, 128, 3))
         self.conv3 = nn.Sequential(_conv_bn_relu(128, 256, 3), _conv_bn_relu(256, 256, 3), _conv_bn_relu(256, 256, 3))

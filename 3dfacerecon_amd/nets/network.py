@@ -80,7 +80,7 @@ class PackedBasis:
             h = _host()
             L = h.lib()
             nbytes = L.fr_decode_backward_basis_bytes(self.nvert, self.ndim_shape, self.ndim_exp)
-            if nbytes == 0:   # a basis the packed kernel does not serve (more than 256 coefficients): reference-layout entry point
+            if nbytes == 0:   # not served by the packed kernel (more than 256 coefficients, or fewer than 16 vertices): reference-layout entry point
                 return None
             buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=self.device)
             with torch.cuda.device(self.device):
@@ -119,10 +119,10 @@ class PackedBasis:
         with torch.cuda.device(dev):
             if self.use_q30():
                 ws = workspace if workspace is not None else torch.empty((self.q30_ws_bytes,), dtype=torch.uint8, device=dev)
-                rc = L.fr_decode_3dmm_q30(h.ptr(params), h.ptr(self.qimage()), h.ptr(R), B, self.nvert, self.ndim_shape,
-                                          self.ndim_exp, float(im_size), h.ptr(out), h.ptr(ws), self.q30_ws_bytes,
-                                          h.stream_ptr(dev))
-                h.check(rc, "fr_decode_3dmm_q30")
+                rc = L.fr_decode_3dmm_q30_lv(h.ptr(params), h.ptr(self.qimage()), h.ptr(R), B, self.nvert, self.ndim_shape,
+                                             self.ndim_exp, float(im_size), h.q30_levels(), h.ptr(out), h.ptr(ws),
+                                             self.q30_ws_bytes, h.stream_ptr(dev))
+                h.check(rc, "fr_decode_3dmm_q30_lv")
             else:
                 rc = L.fr_decode_3dmm(h.ptr(params), h.ptr(self.image), h.ptr(R), B, self.nvert, self.ndim_shape,
                                       self.ndim_exp, float(im_size), h.ptr(out), h.stream_ptr(dev))

@@ -63,28 +63,30 @@ class DecodeRenderPlan:
         self._ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=self.device)
         self._ws_bytes = ws_bytes
         p = h.ptr
-        # The decode arithmetic is fixed when the plan is built: the f32 chain through the fused entry point, or -- when the
-        # opt-in Q30 arithmetic is selected at that moment -- fr_decode_3dmm_q30 (dense rows) with a staging workspace the
-        # PLAN owns, followed by the render phases.  Nothing is allocated at launch time either way, so the plan can be
-        # captured on any stream.
+        # The decode arithmetic is fixed when the plan is built: the f32 chain (fr_decode_render_forward), or -- when the Q30
+        # arithmetic is selected at that moment -- fr_decode_render_forward_q30 with the level count of that moment and a
+        # staging workspace the PLAN owns.  Same phases, same pitched hand-off.  Nothing is allocated at launch time either
+        # way, so the plan can be captured on any stream.  `plan.q30` = 0 (f32 chain) or the Q30 level count (7 / 5 / 4).
         basis = net._basis
-        self.q30 = basis.use_q30()
-        self.pitch = self.N if self.q30 else int(L.fr_decode_render_vertex_pitch(self.N))
+        self.q30 = int(h.q30_levels()) if basis.use_q30() else 0
+        self.pitch = int(L.fr_decode_render_vertex_pitch(self.N))
         self._vertex = torch.empty((self.B, 3, self.pitch), **f32)     # (torch allocations are >= 256-byte aligned)
         self._vertex_bytes = self._vertex.numel() * 4
         self.vertex_proj = self._vertex[:, :, :self.N]                   # [B,3,N]; a strided view when pitch > N
         if self.q30:
             self._q_ws = torch.empty((basis.q30_ws_bytes,), dtype=torch.uint8, device=self.device)
-            self._q_args = (p(self.params), p(basis.qimage()), None, self.B, self.N, net.ndim_shape, net.ndim_exp,
-                            ctypes.c_float(float(net.im_size)), p(self._vertex), p(self._q_ws), basis.q30_ws_bytes)
-            self._ren_args = (p(self._vertex), p(net.tri), p(self.texture), self.B, self.N, self.T, self.H, self.W, 3,
-                              self.tex_batch, p(self.depth), p(self.texture_image), p(self.normal), p(self.tri_ind),
-                              p(self._ws), ws_bytes)
+            self._fused_args = (p(self.params), p(basis.qimage()), None, p(net.tri), p(self.texture), self.B, self.N,
+                                net.ndim_shape, net.ndim_exp, self.T, self.H, self.W, self.tex_batch,
+                                ctypes.c_float(float(net.im_size)), self.q30, p(self._vertex), self._vertex_bytes, p(self.depth),
+                                p(self.texture_image), p(self.normal), p(self.tri_ind), p(self._ws), ws_bytes,
+                                p(self._q_ws), basis.q30_ws_bytes)
+            self._fused_fn, self._fused_name = L.fr_decode_render_forward_q30, "fr_decode_render_forward_q30"
         else:
             self._fused_args = (p(self.params), p(basis.image), None, p(net.tri), p(self.texture), self.B, self.N,
                                 net.ndim_shape, net.ndim_exp, self.T, self.H, self.W, self.tex_batch,
                                 ctypes.c_float(float(net.im_size)), p(self._vertex), self._vertex_bytes, p(self.depth),
                                 p(self.texture_image), p(self.normal), p(self.tri_ind), p(self._ws), ws_bytes)
+            self._fused_fn, self._fused_name = L.fr_decode_render_forward, "fr_decode_render_forward"
         self._graph = None
         # the triangle list is a constant of the model (reference network.py:178): convert + range-check it ONCE into the
         # workspace's table; every step then runs the decode, emit and resolve phases only
@@ -97,19 +99,9 @@ class DecodeRenderPlan:
 
     def _run(self, phases):
         """Phase bits of fr_decode_render_forward: 8 = decode, 4 = pack the triangle list, 1 = emit, 2 = resolve."""
-        if self.q30:   # frozen experiment: its own decode entry point, then the render phases on dense rows
-            if phases & 8:
-                rc = self._L.fr_decode_3dmm_q30(*self._q_args, self._stream())
-                if rc:
-                    self._h.check(rc, "fr_decode_3dmm_q30")
-            if phases & 7:
-                rc = self._L.fr_render_depth_forward_phases(*self._ren_args, self._stream(), phases & 7)
-                if rc:
-                    self._h.check(rc, "fr_render_depth_forward_phases")
-            return
-        rc = self._L.fr_decode_render_forward(*self._fused_args, self._stream(), phases)
+        rc = self._fused_fn(*self._fused_args, self._stream(), phases)
         if rc:
-            self._h.check(rc, "fr_decode_render_forward")
+            self._h.check(rc, self._fused_name)
 
     def pack_tri(self):
         """(Re)builds the pre-validated triangle table in the workspace; call again after changing net.tri in place."""
@@ -131,10 +123,28 @@ class DecodeRenderPlan:
     def outputs(self):
         return self.depth, self.texture_image, self.normal, self.tri_ind
 
+    def _take_params(self, params):
+        """Copies `params` (B,d) into the plan's buffer in the order the launches need.  An unbound plan copies on torch's
+        current stream, where its launches go too.  A plan BOUND to a stream launches there, so the copy must run there as
+        well, behind whatever produced `params` on the current stream: the bound stream waits for the current one, the copy is
+        enqueued on the bound stream, and `params` is marked as used by it (the caller may drop it at once)."""
+        if params is None:
+            return
+        src = params.reshape(self.B, -1)
+        if self.stream is None:
+            self.params.copy_(src, non_blocking=True)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.params.copy_(src, non_blocking=True)
+        if src.is_cuda:
+            src.record_stream(self.stream)
+
     def step(self, params=None):
-        """decode + render of one batch (one C call).  `params` (B,d) is copied into the plan's buffer when given."""
-        if params is not None:
-            self.params.copy_(params.reshape(self.B, -1), non_blocking=True)
+        """decode + render of one batch (one C call).  `params` (B,d) is copied into the plan's buffer when given (on the
+        plan's own stream when it is bound to one: see _take_params).  A bound plan's outputs are complete when ITS stream
+        has run them (`plan.stream.synchronize()`, or `torch.cuda.current_stream().wait_stream(plan.stream)`)."""
+        self._take_params(params)
         self._run(11)
         return self.outputs()
 
@@ -155,10 +165,16 @@ class DecodeRenderPlan:
     def replay(self, params=None):
         if self._graph is None:
             self.capture()
-        if params is not None:
-            self.params.copy_(params.reshape(self.B, -1), non_blocking=True)
+        self._take_params(params)   # (capture() refuses bound plans, so this is the current-stream copy)
         self._graph.replay()
         return self.outputs()
+
+    def __del__(self):   # a bound plan's buffers go back to torch's allocator: not while its stream still runs on them
+        try:
+            if self.stream is not None:
+                self.stream.synchronize()
+        except Exception:
+            pass
 
 
 class BatchesInFlight:
@@ -169,7 +185,7 @@ class BatchesInFlight:
     hardware may run the decode of one beside the render of the other: one batch's kernels fill the tails, launch gaps and
     idle units of the other's.  Measured on an MI355X at 64 faces: 100-103 us per batch against 110 us for one plan stepping
     on one stream (tools/multistream_probe.py; three in flight: slower again -- the batches' working sets evict each other
-    from the 256 MiB Infinity Cache).  The first slot's stream has high priority and the others low: at equal priority the
+    from the 256 MiB Infinity Cache).  The first slot's stream has high priority and the others normal priority: at equal priority the
     streams sometimes lock into step (both decodes, then both emits ... -- 100 to 107 us from one process to the next); with
     one batch entitled to run ahead and the other filling in, 100.5-101.6 us (profiles/round4_probes/r4p).
 
@@ -185,8 +201,10 @@ class BatchesInFlight:
         with torch.cuda.device(self.device):
             self.slots = []
             for i in range(int(slots)):
-                # HIP stream priorities: -1 high, 0 normal, 1 low (out-of-range values are clamped by the runtime)
-                st = torch.cuda.Stream(device=self.device, priority=(-1 if i == 0 else 1))
+                # torch stream priorities on ROCm: negative = high, and anything >= 0 is clamped to 0 = normal (there is no "low"
+                # through this API): slot 0 runs at HIGH priority, the others at NORMAL -- one batch entitled to run ahead, the
+                # other filling in (profiles/round4_probes/r4p: equal priorities sometimes lock the streams into step)
+                st = torch.cuda.Stream(device=self.device, priority=(-1 if i == 0 else 0))
                 self.slots.append(_Slot(net, batch, height, width, texture, stream=st))
             torch.cuda.synchronize(self.device)   # every slot's triangle table is packed before anything else touches the slots
         self._next = 0
@@ -198,11 +216,7 @@ class BatchesInFlight:
         after the resolve (bench.py's per-kernel timing; the step then goes out as three C calls instead of one)."""
         sl = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
-        if params is not None:
-            sl.stream.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(sl.stream):
-                sl.params.copy_(params.reshape(sl.B, -1), non_blocking=True)
-            params.record_stream(sl.stream)   # the caller may drop `params` at once: its memory is not reused before the copy ran
+        sl._take_params(params)   # (on the slot's stream, behind torch's current stream: DecodeRenderPlan._take_params)
         if marks is None:
             sl._run(11)
         else:

@@ -233,11 +233,12 @@ class _RenderingLayerFused(torch.autograd.Function):
         L = h.lib()
         with torch.cuda.device(dev):
             ws_bytes = L.fr_render_depth_workspace_bytes(B, nver, ntri, H, W)
-            ent, _ = _workspace(dev, ws_bytes)
-            ent.tri_ref = ent.tri_key = None   # (this entry point always repacks the triangle table)
-            rc = L.fr_rendering_layer_forward(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), h.ptr(img_c), B, nver, ntri, H, W,
-                                              tex_batch, h.ptr(net_in), h.ptr(depth_img), h.ptr(depth), h.ptr(tri_ind),
-                                              h.ptr(ent.buf), ws_bytes, h.stream_ptr(dev))
+            ent, cached = _workspace(dev, ws_bytes)
+            # the same "pack once while the same `tri` tensor is passed" rule as render_depth (the table is the same table)
+            phases = _render_phases(ent, cached, tri_c, (B, nver, ntri, H, W))
+            rc = L.fr_rendering_layer_forward_phases(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), h.ptr(img_c), B, nver, ntri, H, W,
+                                                     tex_batch, h.ptr(net_in), h.ptr(depth_img), h.ptr(depth), h.ptr(tri_ind),
+                                                     h.ptr(ent.buf), ws_bytes, h.stream_ptr(dev), phases)
         if rc == -4:
             raise NotImplementedError("fused rendering layer: shape only covered by the fallback rasteriser")
         h.check(rc, "fr_rendering_layer_forward")

@@ -176,7 +176,7 @@ def parity_gate(plan, net, assets, params_np, H, W, n_faces, run=True):
                 bad_planes += 1
     R = O.rotation_matrix_batch(params_np[:n, :3])
     # (the oracle of the arithmetic the plan was built with: the f32 chain, or the opt-in Q30 specification)
-    Vo = O.decode_3dmm(params_np[:n], assets["mu"], assets["pc_shape"], assets["pc_exp"], float(H), R=R, q30=bool(plan.q30))
+    Vo = O.decode_3dmm(params_np[:n], assets["mu"], assets["pc_shape"], assets["pc_exp"], float(H), R=R, q30=int(plan.q30))
     Vr = net.vertices_transform(plan.params[:n], R=torch.as_tensor(R, device=plan.device))
     torch.cuda.synchronize(plan.device)
     bad_decode = int(sum(not np.array_equal(Vr[b].cpu().numpy(), Vo[b]) for b in range(n)))
@@ -198,6 +198,34 @@ def parity_gate(plan, net, assets, params_np, H, W, n_faces, run=True):
             "decode_host_rotation_mismatching_faces": bad_decode,
             "decode_inkernel_rotation": {"max_ulp": max_ulp, "frac_bit_equal": frac_equal, "bar": "<= 2 ulp, >= 0.99 equal"},
             "ok": bool(ok)}
+
+
+def clock_probe(L, dev, ms=2.0):
+    """The clock the chip holds in an MFMA-dense loop right now: fr_debug_clock_probe (one 16-wave workgroup per CU issuing the
+    decode's v_mfma_f32_16x16x4_f32 back to back for ~`ms` milliseconds; shader-clock ticks over 100 MHz ticks, per
+    workgroup).  Returns the median over the workgroups in GHz."""
+    import torch
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    iters = max(1, int(ms * 1e-3 * 2.1e9 / (6 * 32 * 4)))
+    ticks = torch.zeros((cus, 2), dtype=torch.int64, device=dev)
+    rc = L.fr_debug_clock_probe(ctypes_ptr(ticks), cus, iters, ctypes_stream(dev))
+    if rc:
+        raise RuntimeError("fr_debug_clock_probe rc=%d" % rc)
+    torch.cuda.synchronize(dev)
+    t = ticks.cpu().double()
+    ghz = (0.1 * t[:, 0] / t[:, 1].clamp(min=1)).sort().values
+    return float(ghz[len(ghz) // 2]), float(ghz[0]), float(ghz[-1])
+
+
+def ctypes_ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ctypes_stream(dev):
+    import ctypes
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def ops_surface_leg(net, ops, plan, B, H, W, K, Wm, R, dist_u, dev):
@@ -257,6 +285,12 @@ def main():
                          "one launch; measured slower, DESIGN.md 4.6).  auto = inflight (measured fastest, DESIGN.md 4.7)")
     ap.add_argument("--in-flight", type=int, default=2, help="slots of the inflight route (2 measured best; 3 is slower again)")
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the serial plan's comparison leg (inflight / pipelined routes)")
+    ap.add_argument("--q30-levels", type=int, default=4, choices=(0, 4, 5, 7),
+                    help="also time the in-flight route with the Q30 decode (int8 matrix cores) at this many digit-product "
+                         "levels, parity-gated against ITS oracle, and report it beside `value` as `q30_inflight` (0 = skip; "
+                         "skipped anyway when FR_DECODE_ARITH already selects Q30 for the whole run, or off the inflight route)")
+    ap.add_argument("--q30-parity-faces", type=int, default=8,
+                    help="faces per slot the Q30 leg's oracle gate checks (its level-by-level oracle takes ~1 s per face)")
     ap.add_argument("--allreduce-mb", type=float, default=-1.0,
                     help="N > 1: time one SUM all-reduce of this many MB on the bench's process group before the timed "
                          "region (config 4's gradient is ~302 MB) and report bus GB/s.  -1 = 302 under nccl, 4 under gloo; 0 = skip")
@@ -308,7 +342,7 @@ def main():
     # auto = the faster route on this hardware: the serial plan (the fused emit || resolve launch measured 112-120 us per step
     # against 111 us: the two roles bind on the same per-CU vector-memory path and do not overlap)
     piped = piped_ok and args.route == "pipelined"
-    inflight = args.route in ("auto", "inflight") and not net._basis.use_q30()
+    inflight = args.route in ("auto", "inflight")
     serial_plan = pipe.DecodeRenderPlan(net, B, H, W)
     serial_plan.params.copy_(torch.as_tensor(params_np, device=dev))
     plan = serial_plan
@@ -396,6 +430,7 @@ def main():
         return blk, blk[med], loc[med], ev_all
 
     blocks, elapsed, local_med, ev_all = timed_blocks(plan, piped, True)
+    clocks = {"after_timed_blocks": clock_probe(L, dev)}   # (straight behind the last timed block: the chip is as warm as it gets)
     per_rank_ms = [1e3 * t / K for t in dist_u.gather_over_ranks(local_med, device=dev)]
     dist_info = dist_u.describe(device=dev)
     faces_per_step = int(round(dist_u.sum_over_ranks(B, device=dev)))   # what the ranks actually ran, counted by the group
@@ -405,6 +440,51 @@ def main():
     serial_ev = []
     if (piped or inflight) and not args.no_serial_leg:
         _, serial_elapsed, _, serial_ev = timed_blocks(serial_plan, False, inflight)
+        clocks["after_serial_leg"] = clock_probe(L, dev)
+
+    # the same in-flight route with the Q30 decode (int8 matrix cores, `--q30-levels` digit-product levels): its own plans,
+    # its own oracle gate -- reported BESIDE `value`, never as it
+    q30_leg = None
+    host = pkg("_lib")
+    if inflight and args.q30_levels and not serial_plan.q30 and net._basis.q30_ws_bytes > 0:
+        prev_arith, prev_lv = host.decode_arith(), host.q30_levels()
+        host.set_decode_arith(host.DECODE_ARITH_Q30, args.q30_levels)
+        try:
+            qplan = pipe.BatchesInFlight(net, B, H, W, slots=max(1, args.in_flight))
+            for sl, pn in zip(qplan.slots, slot_params):
+                sl.params.copy_(torch.as_tensor(pn, device=dev))
+            qserial = pipe.DecodeRenderPlan(net, B, H, W)
+            qserial.params.copy_(torch.as_tensor(params_np, device=dev))
+            torch.cuda.synchronize(dev)
+            qblocks, qelapsed, _, _ = timed_blocks(qplan, False, True)    # (event-bracketed steps like the f32 leg: equal treatment)
+            _, qs_elapsed, _, qs_ev = timed_blocks(qserial, False, True)
+            qpar = None
+            if args.parity_faces != 0:
+                for _ in range(3 * len(qplan.slots)):
+                    qplan.submit()
+                qplan.synchronize()
+                nfq = min(B, max(1, args.q30_parity_faces))
+                per = [parity_gate(sl, net, assets, pn, H, W, nfq, run=False) for sl, pn in zip(qplan.slots, slot_params)]
+                qpar = {"ok": bool(all(q["ok"] for q in per)), "faces_checked": sum(q["faces"] for q in per),
+                        "planes_checked": sum(q["planes_checked"] for q in per),
+                        "mismatching_planes": sum(q["mismatching_planes"] for q in per),
+                        "decode_host_rotation_mismatching_faces": sum(q["decode_host_rotation_mismatching_faces"] for q in per),
+                        "decode_inkernel_rotation_max_ulp": max(q["decode_inkernel_rotation"]["max_ulp"] for q in per),
+                        "oracle": "oracle.decode_3dmm(q30=%d) -- the Q30 specification with %d levels, bit for bit -- and the oracle "
+                                  "rasteriser on the plan's own vertices" % (args.q30_levels, args.q30_levels)}
+                all_q = dist_u.sum_over_ranks(0.0 if qpar["ok"] else 1.0, device=dev) == 0.0
+                if not all_q:
+                    print("bench.py: Q30 PARITY GATE FAILED on rank %d: %s" % (rank, json.dumps(qpar)), file=sys.stderr)
+                    dist_u.barrier()
+                    dist_u.finalize()
+                    sys.exit(3)
+            q30_leg = {"levels": args.q30_levels, "elapsed": qelapsed, "blocks": qblocks, "serial_elapsed": qs_elapsed, "parity": qpar,
+                       "serial_kernels_ms": {"decode (q_stage_kernel + decode_q_ring_kernel)": sum(e[0].elapsed_time(e[1]) for e in qs_ev) / len(qs_ev),
+                                             "raster_emit": sum(e[1].elapsed_time(e[2]) for e in qs_ev) / len(qs_ev),
+                                             "resolve_write": sum(e[2].elapsed_time(e[3]) for e in qs_ev) / len(qs_ev)}}
+            del qplan, qserial
+        finally:
+            host.set_decode_arith(prev_arith, prev_lv)
 
     # the operator-surface route (allocations + pack_tri every call): same K / W / R, reported beside `value`
     ops_elapsed = ops_same = None
@@ -462,6 +542,9 @@ def main():
         emit_ms = sum(e[1].elapsed_time(e[2]) for e in ev_all) / len(ev_all)
         resolve_ms = sum(e[2].elapsed_time(e[3]) for e in ev_all) / len(ev_all)
         fused_ms = None
+    # one batch's parameters-to-planes time inside the timed region (event before its decode -> event behind its resolve)
+    latency_ms = (sum(e[0].elapsed_time(e[3]) for e in ev_all) / len(ev_all)) if not piped else None
+    serial_latency_ms = (sum(e[0].elapsed_time(e[3]) for e in serial_ev) / len(serial_ev)) if serial_ev else None
     cov = float(((plan.slots[0] if inflight else plan).tri_ind >= 0).float().mean().item())
     if inflight and serial_ev:
         # Two batches in flight: a kernel's event-bracketed duration in THAT region measures how the two streams share the
@@ -517,11 +600,12 @@ def main():
                            "hbm_GBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9,
                            "hbm_frac_of_8TBs": ab["decode"] * B / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "algorithmic_bytes_per_launch": ab["decode"] * B,
-                           "which_side_binds": "priced against the fp32 MFMA peak because the flops put it at the ridge "
-                               "(29.6 us of MFMA vs 23.4 us of HBM at the spec peaks), but the ablation says the MEMORY side "
-                               "binds: the kernel with its MFMAs removed takes 50-53 us, with its stores removed 47 us, "
-                               "MFMA-only 36 us at the 2.1 GHz it holds (DESIGN.md 4.1, profiles/round3_decode_breakdown.json): "
-                               "read `frac` as matrix-pipe utilisation and hbm_frac_of_8TBs as the HBM roofline fraction"}
+                           "which_side_binds": "THIS KERNEL ALONE: priced against the fp32 MFMA peak because the flops put it at the "
+                               "ridge (29.6 us of MFMA vs 23.4 us of HBM at the spec peaks), but the ablation says its MEMORY side "
+                               "binds: with its MFMAs removed it takes 50-53 us, with its stores removed 47 us, MFMA-only 36 us at "
+                               "the clock it holds (DESIGN.md 4.1, profiles/round3_decode_breakdown.json): read `frac` as "
+                               "matrix-pipe utilisation and hbm_frac_of_8TBs as the HBM roofline fraction.  THE STEP is another "
+                               "question, answered under `vector_pipe.is`"}
         kernels = {"decode": roof_decode}
         if piped:
             render_bytes = emit_bytes + resolve_bytes
@@ -556,14 +640,24 @@ def main():
                             r["rocprofv3_avg_ms"] = rec["rocprofv3_avg_ms"]
                 vp = pmc.get("vector_pipe")
                 if isinstance(vp, dict):   # what the step asks of the vector ALUs (f32 MFMA included: it runs there)
-                    vector_pipe = {"cycles_per_simd_per_step": vp["step_cycles_per_simd"], "us_at_2.1GHz": vp["step_us_at_2.1GHz"],
+                    ghz = clocks["after_timed_blocks"][0]
+                    us_held = vp["step_cycles_per_simd"] / (ghz * 1e3)
+                    vector_pipe = {"cycles_per_simd_per_step": vp["step_cycles_per_simd"], "clock_GHz_held": ghz,
+                                   "us_at_clock_held": us_held, "us_at_2.1GHz": vp["step_us_at_2.1GHz"],
                                    "per_kernel_cycles_per_simd": {k: vp[k]["cycles_per_simd"] for k in ("decode", "raster_emit", "resolve_write")},
-                                   "frac_of_ms_per_step": vp["step_us_at_2.1GHz"] * 1e-3 / (1e3 * elapsed / K),
+                                   "frac_of_ms_per_step": us_held * 1e-3 / (1e3 * elapsed / K),
                                    "is": "PMC instruction counts of the three kernels (profiles/pmc_traffic.json: 32 cycles per "
-                                         "v_mfma_f32_16x16x4_f32, 4 per other wave64 vector instruction, per SIMD) against the measured "
-                                         "step: the share of the step the vector pipe alone accounts for.  The f32-input MFMA and every "
-                                         "other vector instruction of a SIMD take turns (profiles/round4_probes/r4t), so this pipe, not "
-                                         "HBM, is what the step is closest to"}
+                                         "v_mfma_f32_16x16x4_f32, 4 per other wave64 vector instruction, per SIMD) at the clock the "
+                                         "probe of THIS run read (clock_GHz_held), against the measured step: the share of the step "
+                                         "the vector pipe alone accounts for.  Round 4 read this pipe as what the step is closest to "
+                                         "(the f32-input MFMA and every other vector instruction of a SIMD take turns: r4t).  Round 5 "
+                                         "tested that reading and it does NOT hold for the step: a decode with a third of the f32 "
+                                         "kernel's vector-pipe time (Q30, ten int8 digit products; `q30_inflight`) moves the in-flight "
+                                         "step by 1-3 us, not by the 15 us of pipe time it frees, and a decode slimmed to co-reside "
+                                         "with the other batch's emit workgroups makes it 9 us longer (profiles/round5_probes/r5b).  "
+                                         "What binds the in-flight step is that each kernel fills every CU's registers / wave slots by "
+                                         "itself -- the two batches alternate on a CU instead of sharing it -- and the ~385 MB a step "
+                                         "moves; the pipe's share is an account, not the bound"}
         except (OSError, ValueError, KeyError):
             pass
         for name, r in kernels.items():
@@ -591,6 +685,23 @@ def main():
             "value": value, "unit": "faces/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": args.scaling,
             "repeats": R, "value_is": "median over %d timed blocks of K steps each" % R, "route": route,
+            "value_route": "inflight" if inflight else ("pipelined" if piped else "serial"),
+            "value_meaning": ("THROUGHPUT of independent batches: K batches go from parameters to planes between the brackets with "
+                              "%d in flight at any time; ms_per_step is the interval between finished batches, NOT one batch's "
+                              "latency (per_batch_latency_ms).  A dependent loop (CoarseNet -> render -> CoarseNet, "
+                              "nets/network.py:113-116) gets config.value_one_batch_at_a_time, the serial plan's figure, which is "
+                              "also the one comparable with rounds 1-3" % len(plan.slots)) if inflight else
+                             "one batch at a time: ms_per_step is also one batch's parameters-to-planes time",
+            "per_batch_latency_ms": latency_ms,
+            "per_batch_latency_is": "mean over the event-bracketed steps of the timed blocks: HIP event before the batch's decode launch "
+                                    "-> event behind its resolve, on the batch's own stream" + (
+                                        "; the same for the serial leg: %.4f ms" % serial_latency_ms if serial_latency_ms is not None else ""),
+            "clock_GHz_held": {k: {"median": v[0], "min": v[1], "max": v[2]} for k, v in clocks.items()},
+            "clock_GHz_held_is": "fr_debug_clock_probe: ~2 ms of back-to-back v_mfma_f32_16x16x4_f32 on 16 waves per CU (the decode's "
+                                 "instruction and occupancy), shader-clock ticks / 100 MHz ticks per workgroup, launched straight behind "
+                                 "the timed blocks (and behind the serial leg): the clock THIS part holds under matrix load today -- "
+                                 "parts differ by several per cent, which is what moves the in-flight figure from box to box "
+                                 "(DESIGN.md 4.7)",
             "value_min": faces_per_step * K / max(blocks), "value_max": faces_per_step * K / min(blocks),
             "ms_per_step_min": 1e3 * min(blocks) / K, "ms_per_step_max": 1e3 * max(blocks) / K,
             "blocks_ms_per_step": [round(1e3 * t / K, 5) for t in blocks],   # every timed block, in the order they ran
@@ -598,6 +709,8 @@ def main():
             "config": {"workload": "configs[1]: batch %d random 235-d params -> 3DMM decode -> depth render, "
                                    "%dx%d, fp32, all four output planes" % (args.batch, H, W),
                        "faces_per_gpu": B if args.scaling == "weak" else None, "faces_per_step_all_gpus": faces_per_step,
+                       "value_one_batch_at_a_time": (faces_per_step * K / serial_elapsed) if serial_elapsed is not None else
+                                                    (value if not (inflight or piped) else None),
                        "faces_per_gpu_rank0": B, "batches_in_flight": len(plan.slots) if inflight else (2 if piped else 1), "nver": N, "ntri": T, "n_shape": net.ndim_shape, "n_exp": net.ndim_exp,
                        "sampler": "sample_test.py:23-38 beta=0.7 " + ("seed=3456+rank" if args.scaling == "weak" else "seed=3456, one batch for all ranks"), "coverage": cov,
                        "sharding": ("weak: every rank runs its own %d faces" % B if args.scaling == "weak" else
@@ -630,12 +743,34 @@ def main():
             out["serial_plan"] = {"ms_per_step": 1e3 * serial_elapsed / K, "timed_route_vs_serial": serial_elapsed / elapsed,
                                   "route": "DecodeRenderPlan.step(): decode -> emit -> resolve, three launches, same process, "
                                            "same K / W / R (median block)"}
+        if q30_leg is not None:
+            qv = faces_per_step * K / q30_leg["elapsed"]
+            out["q30_inflight_faces_per_s"] = qv
+            out["q30_inflight"] = {
+                "decode_arith": "Q30 fixed point on the int8 matrix cores, %d digit-product levels (include/fr_hotpath.h: "
+                                "fr_decode_render_forward_q30)" % q30_leg["levels"],
+                "ms_per_step": 1e3 * q30_leg["elapsed"] / K, "vs_value": qv / value,
+                "ms_per_step_min": 1e3 * min(q30_leg["blocks"]) / K, "ms_per_step_max": 1e3 * max(q30_leg["blocks"]) / K,
+                "frac_of_8TBs": ab["pipeline"] * qv / world / 1e9 / HBM_PEAK_GBS,
+                "serial_plan_ms_per_step": 1e3 * q30_leg["serial_elapsed"] / K,
+                "serial_plan_faces_per_s": faces_per_step * K / q30_leg["serial_elapsed"],
+                "serial_leg_kernels_avg_ms": q30_leg["serial_kernels_ms"],
+                "parity": q30_leg["parity"],
+                "why_not_value": "the two arithmetics are two written definitions of the same blend, each held to its own CPU "
+                                 "restatement bit for bit; `value` stays on the f32 chain (the reference's arithmetic type, the "
+                                 "figure rounds 1-4 reported).  Same route, same K / W / R, same slots' parameters"}
         if allreduce is not None:
             out["dist"]["allreduce_preflight"] = allreduce
         if args.scaling == "strong":   # what one GPU's shard was measured to take (profiles/round3_strong_scaling_shards.json)
+            try:
+                sh = json.load(open(os.path.join(ROOT, "profiles", "round3_strong_scaling_shards.json")))["shards"]
+                us = {k.split("(")[1].split()[0]: v["us_per_step"] for k, v in sh.items()}
+                sp = {k.split("=")[1].split()[0]: v["predicted_speedup_vs_1_gpu"] for k, v in sh.items()}
+            except (OSError, ValueError, KeyError, IndexError):
+                us = sp = None
             out["dist"]["strong_scaling_prediction"] = {
-                "us_per_step_at_faces_per_gpu": {"64": 116.6, "32": 78.9, "16": 65.6, "8": 57.1},
-                "predicted_speedup_vs_1_gpu": {"1": 1.0, "2": 1.48, "4": 1.78, "8": 2.04},
+                "us_per_step_at_faces_per_gpu": us,
+                "predicted_speedup_vs_1_gpu": sp,
                 "why": "every rank streams the whole 153 MB basis whatever its share of the batch, and each render kernel "
                        "keeps ~10 us of latency chain: strong scaling of ONE 64-face batch is structurally poor; the "
                        "path is meant to scale weakly (64 faces per GPU, no collective)",

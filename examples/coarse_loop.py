@@ -11,6 +11,9 @@ full forward on a validation batch every iteration) with synthetic images / labe
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29501 \
         examples/coarse_loop.py --batch 32 --steps 5 --train                  # config 4: 256 faces over 8 GPUs
     ... --im-size 448 --batch 16 --fine                                       # config 5: Coarse + Fine joint forward
+    python examples/coarse_loop.py --phase test --batch 64 --steps 20         # the reference's eval loop (trainval.py:192-210):
+                                                                              # independent test batches, the depth rendering of
+                                                                              # batch k in flight beside the network of batch k+1
 
 The render / decode path needs no collective (the batch is sharded); the only collectives are DDP's gradient all-reduce
 and -- with --gather-sfs -- the all-gather that restores the reference's whole-batch lighting estimate of the
@@ -37,6 +40,7 @@ def pkg(n):
 def build_harness(args, dev, rank, world, local):
     """model (DDP-wrapped when training on > 1 rank), optimiser, step() closure."""
     synth, netm, cn, losses = pkg("utils.synth"), pkg("nets.network"), pkg("nets.coarse_net"), pkg("nets.losses")
+    cn.apply_miopen_workaround()   # a process setting, applied by the entry point before the first convolution (INTEGRATION.md)
     torch.manual_seed(1234)  # same initial weights on every rank
     A = synth.make_small_assets() if args.small else synth.make_assets()
     B, S = args.batch, args.im_size
@@ -81,6 +85,73 @@ def build_harness(args, dev, rank, world, local):
     return model, net, opt, step
 
 
+def run_test_phase(args, dev, rank, world, local, dist_u):
+    """The reference's evaluation loop (trainval.py:192-210: `while True: images = next(generator); pred_depth = sess.run(...);
+    write depth * 255`) over INDEPENDENT test batches.  CoarseNet of a batch is a dependent chain (network -> decode -> render ->
+    network, nets/network.py:113-116) and runs as such on torch's current stream; the batch's final depth rendering
+    (depth_rendering_layer, network.py:300-309: decode + render of the predicted parameters) does not feed anything of the NEXT
+    batch, so it goes down `pipeline.BatchesInFlight.submit(pred_params)` -- its own stream, two batches in flight -- and its
+    consumer (the reference writes depth * 255 to a jpg; here: the same product, reduced to a checksum) is ordered behind the slot
+    with `make_current_stream_wait()` one iteration later, i.e. the render of batch k runs beside the network of batch k + 1."""
+    synth, netm, cn, pipe = pkg("utils.synth"), pkg("nets.network"), pkg("nets.coarse_net"), pkg("pipeline")
+    cn.apply_miopen_workaround()
+    torch.manual_seed(1234)
+    A = synth.make_small_assets() if args.small else synth.make_assets()
+    B, S = args.batch, args.im_size
+    face = netm.FaceRecNet(mesh_data=A, batch_size=B, im_size=S, device=dev)
+    if args.small:
+        face.init_pred_params[..., 6] = 1e-3 * S / 200.0
+    coarse = cn.CoarseNet(face, nIter=args.nIter).to(dev).eval()
+    flights = pipe.BatchesInFlight(face, B, S, S, slots=2)
+    g = torch.Generator(device="cpu").manual_seed(100 + rank)
+    images = [torch.rand((B, S, S, 1), generator=g).to(dev) for _ in range(4)]   # the "test generator": four resident batches
+
+    def consume(slot):
+        """trainval.py:196: depth_images = pred_depth * 255.0, one image per face (written to disk there)."""
+        slot.make_current_stream_wait()
+        return (slot.depth.clamp_min(1e-6) * 255.0).sum(dim=(1, 2, 3))
+
+    def loop(n):
+        sums, pending = [], None
+        with torch.no_grad():
+            for k in range(n):
+                params = coarse(images[k % len(images)])           # the dependent chain of THIS batch (current stream)
+                slot = flights.submit(params)                       # its depth rendering: the slot's stream, nothing waits for it yet
+                if pending is not None:
+                    sums.append(consume(pending))                   # batch k-1's planes, behind ITS slot
+                pending = slot
+            sums.append(consume(pending))
+        return sums
+
+    loop(max(args.warmup, 1))
+    torch.cuda.synchronize(dev)
+    dist_u.barrier()
+    t0 = time.perf_counter()
+    sums = loop(args.steps)
+    torch.cuda.synchronize(dev)
+    dt = dist_u.max_over_ranks(time.perf_counter() - t0, device=dev)
+    # the same batches one at a time through the plain surface: the in-flight loop must reproduce them bit for bit
+    with torch.no_grad():
+        ref = []
+        for k in range(min(args.steps, len(images))):
+            p = coarse(images[k])
+            d = face.coarse_net_input(face.vertices_transform(p), im_gray=images[k])[1]
+            ref.append((d * 255.0).sum(dim=(1, 2, 3)))
+    same = all(torch.equal(a, b) for a, b in zip(sums, ref))
+    dist_info = dist_u.describe(device=dev)
+    if rank == 0:
+        print(json.dumps({"metric": "faces/sec, evaluation loop (trainval.py:192-210): CoarseNet x %d + depth rendering" % args.nIter,
+                          "value": world * B * args.steps / dt, "unit": "faces/s", "higher_is_better": True, "data": "synthetic",
+                          "dtype": "f32", "phase": "test", "n_gpus": world, "faces_per_gpu": B, "im_size": S, "steps": args.steps,
+                          "ms_per_step": 1e3 * dt / args.steps, "batches_in_flight": len(flights.slots),
+                          "route": "CoarseNet on torch's current stream; depth_rendering_layer of batch k through "
+                                   "pipeline.BatchesInFlight.submit() beside the network of batch k + 1; consumer ordered with "
+                                   "make_current_stream_wait()",
+                          "depth_identical_to_one_batch_at_a_time": bool(same), "dist": dist_info}))
+    dist_u.finalize()
+    return 0 if same else 1
+
+
 # BASELINE.json configs[2..4] as presets; the global batch is cut over the ranks that are present (one process per GPU)
 CONFIG_PRESETS = {
     3: dict(label="configs[2]: CoarseNet (ResNet-101) + render_depth end-to-end forward, batch 32, 1 GPU",
@@ -116,9 +187,16 @@ def main():
     ap.add_argument("--fine", action="store_true")
     ap.add_argument("--gather-sfs", action="store_true", help="whole-batch SfS lighting estimate across ranks")
     ap.add_argument("--small", action="store_true", help="tiny synthetic assets (smoke runs)")
+    ap.add_argument("--phase", choices=("train", "test"), default="train",
+                    help="trainval.py's phase switch (:223-225).  test = the forward-only evaluation loop over independent batches "
+                         "with the depth rendering in flight (run_test_phase); train = everything else this script does")
     args = ap.parse_args()
     dist_u = pkg("utils.dist")
     world, rank, local = dist_u.init_from_env()
+    if args.phase == "test":
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        sys.exit(run_test_phase(args, dev, rank, world, local, dist_u))
     preset = None
     if args.config is not None:
         preset = CONFIG_PRESETS[args.config]

@@ -108,6 +108,14 @@ int fr_rendering_layer_forward(const float* vertex, const float* tri, const floa
                                float* depth_img, float* depth, float* tri_ind, void* workspace, size_t ws_bytes,
                                void* hip_stream);
 
+/* The same phase by phase (bits as in fr_render_depth_forward_phases: 4 = pack the triangle list, 1 = emit, 2 = the fused
+ * resolve): a caller whose triangle list is a model constant (nets/network.py:178) packs once and runs phases = 3 per call
+ * (rendering_layer/ops.py does, under the same tensor-identity rule as render_depth). */
+int fr_rendering_layer_forward_phases(const float* vertex, const float* tri, const float* texture, const float* im_gray,
+                                      int B, int nver, int ntri, int H, int W, int tex_batch, float* net_input,
+                                      float* depth_img, float* depth, float* tri_ind, void* workspace, size_t ws_bytes,
+                                      void* hip_stream, int phases);
+
 /* ---- render_depth backward -----------------------------------------------------------------------------
  * Replaces RenderDepthOpGrad::Compute + functor RenderDepthGrad (render_depth_op.cc:470-528, 325-368;
  * render_depth_op.cu.cc:345-423) reached from the gradient registration at rendering_layer/ops.py:86-95.
@@ -196,22 +204,39 @@ int fr_decode_render_pipelined(const float* params, const void* packed_basis, co
                                float* depth, float* tex_img, float* normal, float* tri_ind, void* workspace_new,
                                void* workspace_prev, size_t ws_bytes, void* hip_stream, int phases);
 
-/* Opt-in second definition of the same decode (frozen experiment; nothing of it is built, allocated or
- * launched unless these entry points are called):
- *   Q30: v = fl32(mu + S + E) with S + E an EXACT fixed-point dot product of the operands quantised to 31 bits against
- *   power-of-two row / column scales (int8 matrix cores, 16 digit products): the correctly rounded fp32 value of the
- *   real-number blend in > 99 % of the cases (half the f32 chain's mean error); a non-finite parameter makes the face's
- *   vertices NaN.  Measured 2-11 % slower than fr_decode_3dmm inside the 64-face pipeline, hence not the default.
+/* Second definition of the same decode (nothing of it is built, allocated or launched unless these entry
+ * points are called):
+ *   Q30: v = fl32(mu + S + E) with S + E a fixed-point dot product of the operands quantised to 31 bits against power-of-two
+ *   row / column scales, evaluated on the int8 matrix cores as products of base-256 digits.  `levels` = how many of the seven
+ *   digit-product levels are kept: 7 = all sixteen products (the EXACT product of the quantised operands: the correctly
+ *   rounded fp32 value of the real-number blend in > 99 % of the cases, half the f32 chain's mean error), 5 = the thirteen
+ *   products of weight >= 2^-32 of full scale (what is dropped is below 2^-38 of a term's scale: the same fp32 result in
+ *   > 99.98 % of the cases), 4 = the ten products of weight >= 2^-24 (dropped: below 2^-30; mean error 0.29 ulp against 0.26
+ *   for the exact product and 0.34 - 0.5 for the f32 chain).  Integer arithmetic: order-independent, restated bit for bit in
+ *   oracle/fr_oracle.c ("Q30 decode", the same `levels`).  A non-finite parameter makes the face's vertices NaN.
  * It has its own basis image (fr_decode_q30_image_bytes, 256-byte aligned; 0 = shape not covered: n_shape + n_exp > 512,
- * for which fr_decode_q30_pack / fr_decode_3dmm_q30 return FR_ERR_UNSUPPORTED) and needs a caller-owned staging
- * workspace (fr_decode_q30_workspace_bytes: 68 KiB for the model's shape, 16-byte aligned) that must not be shared by
- * launches in flight on different streams.  Restated in oracle/fr_oracle.c ("Q30 decode"), held bit for bit. */
+ * for which fr_decode_q30_pack / fr_decode_3dmm_q30 return FR_ERR_UNSUPPORTED; the image does not depend on `levels`) and
+ * needs a caller-owned staging workspace (fr_decode_q30_workspace_bytes: 68 KiB for the model's shape, 16-byte aligned) that
+ * must not be shared by launches in flight on different streams.  fr_decode_3dmm_q30 is levels = 7 on dense [B,3,N] rows.
+ * FR_Q30_SCHED (fr_set_option): 0 = 8 waves per CU, whole tiles, 16-deep ring, behind a staging launch (default) | 1 = the same
+ * with the parameter digits staged inside the kernel | 2 = 16 waves per CU, a tile's two 32-column halves on neighbouring
+ * waves; no result bit depends on it (profiles/round5_probes/r5b: what each measured). */
 size_t fr_decode_q30_image_bytes(int N, int n_shape, int n_exp);
 int fr_decode_q30_pack(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
                        void* qimage, size_t qimage_bytes, void* hip_stream);
 size_t fr_decode_q30_workspace_bytes(int n_shape, int n_exp);
 int fr_decode_3dmm_q30(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
                        int n_exp, float im_size, float* vertex_proj, void* workspace, size_t ws_bytes, void* hip_stream);
+int fr_decode_3dmm_q30_lv(const float* params, const void* qimage, const float* R_override, int B, int N, int n_shape,
+                          int n_exp, float im_size, int levels, float* vertex_proj, void* workspace, size_t ws_bytes,
+                          void* hip_stream);
+/* fr_decode_render_forward with the Q30 decode (same phases, same pitched vertex hand-off, same render workspace; q_workspace =
+ * the decode's staging buffer, one per stream in flight). */
+int fr_decode_render_forward_q30(const float* params, const void* qimage, const float* R_override, const float* tri,
+                                 const float* texture, int B, int N, int n_shape, int n_exp, int ntri, int H, int W,
+                                 int tex_batch, float im_size, int levels, float* vertex_handoff, size_t vertex_bytes,
+                                 float* depth, float* tex_img, float* normal, float* tri_ind, void* workspace, size_t ws_bytes,
+                                 void* q_workspace, size_t q_ws_bytes, void* hip_stream, int phases);
 
 /* ---- 3DMM decode backward (the gradient TF autodiff derives from nets/network.py:140-171) ------------
  *   grad_vertex_proj [B,3,N] = dL/d vertex_proj;  vertex_proj [B,3,N] = the forward output (used for d f);
@@ -242,7 +267,10 @@ int fr_decode_3dmm_backward(const float* grad_vertex_proj, const float* params, 
  * reaches global memory.  rocprofv3 at 64 faces: 27.6 + 59.4 + 16.7 us (round 3) -> 70.1 + 6.9 us.  Same workspace
  * (fr_decode_backward_workspace_bytes), same definition of every output, deterministic (bit-reproducible for a given
  * FR_BWD_CHUNKS); the two entry points sum their partial results in different (each fixed) orders, so they agree to rounding,
- * not bit for bit. */
+ * not bit for bit.
+ * fr_decode_backward_basis_bytes answers 0 -- and the pack / packed entry points FR_ERR_UNSUPPORTED -- for what the fused kernel
+ * does not serve: more than 256 coefficients, or a mesh of fewer than 16 vertices (its tile loads are sixteen floats wide); use
+ * fr_decode_3dmm_backward there. */
 size_t fr_decode_backward_basis_bytes(int N, int n_shape, int n_exp);
 int fr_decode_backward_pack_basis(const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp, void* packed_t,
                                   size_t packed_bytes, void* hip_stream);
@@ -261,6 +289,12 @@ void fr_debug_render_geom(int B, int ntri, int H, int W, int rows_override, int*
  * to the device word `mismatches`.  Used by tests/test_render_gpu.py (all 2^32 patterns). */
 int fr_debug_div3_sweep(unsigned long long first, unsigned long long count, unsigned long long* mismatches,
                         void* hip_stream);
+
+/* Measurement hook (bench.py `clock_GHz_held`; no reference counterpart): `blocks` 1,024-thread workgroups each issue
+ * `iters` x 6 v_mfma_f32_16x16x4_f32 per wave (the decode's matrix instruction at the decode's occupancy) and write
+ * ticks[2 b] = shader-clock ticks and ticks[2 b + 1] = 100 MHz ticks their loop took (device buffer of 2 * blocks 64-bit
+ * words): clock held = 0.1 GHz * ticks[2 b] / ticks[2 b + 1]. */
+int fr_debug_clock_probe(unsigned long long* ticks, int blocks, int iters, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -487,10 +487,13 @@ int fr_oracle_decode_3dmm_backward_f64(const float* grad_vertex_proj, const floa
  *   qA    = rint(A'[r,k] 2^(30-re_r))                  (|qA| <= 2^30; entries within 2^-6 of the row maximum are exact)
  *   be    = max_k (frexp exponent of x_k) + ce_k       (0 if x == 0)                   -> x'_k = x_k 2^ce_k
  *   qB    = rint(x'_k 2^(30-be))
- *   I     = sum_k qA qB   evaluated as seven level sums L_s = sum_k sum_{i+j=s} a_i b_j over the balanced base-256
- *           digits of qA, qB (most significant first), combined as h = fl64(h*256 + L_s), s = 0..6 -- exact whenever
- *           |I| < 2^53, correctly rounded steps otherwise
- *   v_r   = fl32( fl64( mu_r + h 2^(re_r+be-60) ) )    -- ONE rounding of mu + S + E instead of the chain's ~K
+ *   I     = sum_k qA qB   evaluated as level sums L_s = sum_k sum_{i+j=s} a_i b_j over the balanced base-256 digits of
+ *           qA, qB (most significant first; digit product a_i b_j has weight 256^(6-i-j)), s = 0 .. LV-1, combined as
+ *           h = fl64(h*256 + L_s) -- exact whenever the integer stays below 2^53, correctly rounded steps otherwise.
+ *           LV = 7 keeps all sixteen digit products (the exact product of the two 31-bit operands); LV = 5 keeps the
+ *           thirteen products with i + j <= 4 (what is dropped is below 2^-38 of a term's full scale: the fp32 result
+ *           is unchanged in > 99.98 % of the cases); LV = 4 the ten with i + j <= 3 (dropped: below 2^-30 of full scale)
+ *   v_r   = fl32( fl64( mu_r + h 2^(re_r+be-60+8(7-LV)) ) )    -- ONE rounding of mu + S + E instead of the chain's ~K
  *   then the pose product and y flip exactly as fr_decode_body.
  * A non-finite parameter makes the face's vertices NaN, a non-finite basis entry its row's. */
 static int fr_q30_exp(double x) { int e; frexp(x, &e); return e; }
@@ -502,10 +505,11 @@ static void fr_q30_digits(int32_t q, int d[4]) {
     }
     d[0] = q;
 }
-int fr_oracle_decode_3dmm_q30(const float* params, const float* mu, const float* pc_shape, const float* pc_exp,
-                              const float* R_override, int B, int N, int ns, int ne, float im_size,
-                              float* vertex_proj) {
-    if (B < 0 || N < 0 || ns < 0 || ne < 0) return -1;
+int fr_oracle_decode_3dmm_q30_lv(const float* params, const float* mu, const float* pc_shape, const float* pc_exp,
+                                 const float* R_override, int B, int N, int ns, int ne, float im_size, int levels,
+                                 float* vertex_proj) {
+    if (B < 0 || N < 0 || ns < 0 || ne < 0 || levels < 1 || levels > 7) return -1;
+    const int LV = levels;
     const int K = ns + ne, nd = 7 + K;
     const size_t rows = (size_t)3 * N;
     int* ce = (int*)calloc(K > 0 ? K : 1, sizeof(int));
@@ -561,7 +565,23 @@ int fr_oracle_decode_3dmm_q30(const float* params, const float* mu, const float*
             for (int b = 0; b < B; b++) {
                 const int32_t* qb = qB + (size_t)b * K;
                 __int128 I = 0;
-                for (int k = 0; k < K; k++) I += (__int128)((int64_t)qA[k] * (int64_t)qb[k]);
+                if (LV == 7) {
+                    for (int k = 0; k < K; k++) I += (__int128)((int64_t)qA[k] * (int64_t)qb[k]);
+                } else {
+                    /* kept products: a_i 256^(3-i) times the top LV-i digits of qB (T[i]; all four when LV-i >= 4) */
+                    for (int k = 0; k < K; k++) {
+                        int da[4], db[4];
+                        fr_q30_digits(qA[k], da);
+                        fr_q30_digits(qb[k], db);
+                        for (int i = 0; i < 4 && i < LV; i++) {
+                            int64_t T = 0;
+                            for (int j = 0; j < 4 && i + j < LV; j++) T += (int64_t)db[j] << (8 * (3 - j));
+                            I += (__int128)(((int64_t)da[i] << (8 * (3 - i))) * T);
+                        }
+                    }
+                    /* every kept product is a multiple of 256^(7-LV) */
+                    I /= ((__int128)1 << (8 * (7 - LV)));
+                }
                 double h;
                 const __int128 lim = (__int128)1 << 52;
                 if (I < lim && I > -lim) {
@@ -576,9 +596,9 @@ int fr_oracle_decode_3dmm_q30(const float* params, const float* mu, const float*
                             for (int j = 0; j < 4; j++) L[i + j] += (int64_t)da[i] * db[j];
                     }
                     h = (double)L[0];
-                    for (int s = 1; s < 7; s++) h = h * 256.0 + (double)L[s];
+                    for (int s = 1; s < LV; s++) h = h * 256.0 + (double)L[s];
                 }
-                double d = (double)mu[r] + ldexp(h, re + be[b] - 60);
+                double d = (double)mu[r] + ldexp(h, re + be[b] - 60 + 8 * (7 - LV));
                 v[(size_t)b * 3 + c] = (badr || badb[b]) ? NAN : (float)d;
             }
         }
@@ -597,4 +617,10 @@ int fr_oracle_decode_3dmm_q30(const float* params, const float* mu, const float*
 #undef FR_A
     free(ce); free(qB); free(qA); free(be); free(badb); free(v); free(Ms);
     return 0;
+}
+
+int fr_oracle_decode_3dmm_q30(const float* params, const float* mu, const float* pc_shape, const float* pc_exp,
+                              const float* R_override, int B, int N, int ns, int ne, float im_size,
+                              float* vertex_proj) {
+    return fr_oracle_decode_3dmm_q30_lv(params, mu, pc_shape, pc_exp, R_override, B, N, ns, ne, im_size, 7, vertex_proj);
 }

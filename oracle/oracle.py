@@ -58,6 +58,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = [_f32p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_float, _f32p]
             fn.restype = ctypes.c_int
+        L.fr_oracle_decode_3dmm_q30_lv.argtypes = [_f32p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, _f32p]
+        L.fr_oracle_decode_3dmm_q30_lv.restype = ctypes.c_int
         L.fr_oracle_decode_3dmm_f64.argtypes = [_f32p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_double, _f64p]
         L.fr_oracle_decode_3dmm_f64.restype = ctypes.c_int
         L.fr_oracle_decode_3dmm_backward_f64.argtypes = [_f32p] * 5 + [ctypes.c_int] * 4 + [_f64p]
@@ -157,7 +159,8 @@ def rotation_matrix_batch(angles_batch):
 
 def decode_3dmm(params, mu, pc_shape, pc_exp, im_size, R=None, nofma=False, q30=False):
     """CPU restatement of FaceRecNet.vertices_transform (nets/network.py:140-171) under the written fp32 spec
-    (q30=True: under the written fixed-point spec of the product's int8-MFMA decode, fr_oracle.c "Q30 decode")."""
+    (q30=True or a level count 4 / 5 / 7: under the written fixed-point spec of the product's int8-MFMA decode, fr_oracle.c
+    "Q30 decode"; True = 7 = all sixteen digit products)."""
     params, pp = _c32(params)
     mu, mp = _c32(np.asarray(mu).reshape(-1))
     pc_shape, sp = _c32(pc_shape)
@@ -173,15 +176,20 @@ def decode_3dmm(params, mu, pc_shape, pc_exp, im_size, R=None, nofma=False, q30=
     out = np.empty((B, 3, N), np.float32)
     fn = lib().fr_oracle_decode_3dmm_nofma if nofma else lib().fr_oracle_decode_3dmm
     if q30:
-        fn = lib().fr_oracle_decode_3dmm_q30
-    rc = fn(pp, mp, sp, ep, rp, B, N, ns, ne, float(im_size), out.ctypes.data_as(_f32p))
+        levels = 7 if q30 is True else int(q30)
+        rc = lib().fr_oracle_decode_3dmm_q30_lv(pp, mp, sp, ep, rp, B, N, ns, ne, float(im_size), levels,
+                                                out.ctypes.data_as(_f32p))
+    else:
+        rc = fn(pp, mp, sp, ep, rp, B, N, ns, ne, float(im_size), out.ctypes.data_as(_f32p))
     if rc != 0:
         raise ValueError("fr_oracle_decode_3dmm rc=%d" % rc)
     return out
 
 
-def decode_3dmm_q30(params, mu, pc_shape, pc_exp, im_size, R=None):
-    return decode_3dmm(params, mu, pc_shape, pc_exp, im_size, R=R, q30=True)
+def decode_3dmm_q30(params, mu, pc_shape, pc_exp, im_size, R=None, levels=7):
+    if not 1 <= int(levels) <= 7:
+        raise ValueError("Q30 levels must be in 1..7")
+    return decode_3dmm(params, mu, pc_shape, pc_exp, im_size, R=R, q30=int(levels))
 
 
 def decode_3dmm_f64(params, mu, pc_shape, pc_exp, im_size):

@@ -5,8 +5,8 @@ import sys
 import numpy as np
 import pytest
 
-# (see nets/coarse_net.py: a MIOpen solver that faults on gfx950 while convolutions are being benchmarked; set here as well so
-# that it holds for every convolution of the session, whichever module runs one first)
+# (nets/coarse_net.py, apply_miopen_workaround: a MIOpen solver that faults on gfx950 while convolutions are being benchmarked.  A
+# process setting, so it is the ENTRY POINT's to make -- for the test session that is here, before anything runs a convolution)
 os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

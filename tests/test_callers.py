@@ -44,6 +44,31 @@ def _ddp_worker(rank, world, port, q):
     d.finalize()
 
 
+def test_miopen_workaround_is_the_entry_points_job(monkeypatch):
+    """importing nets.coarse_net must not touch the process environment (the MIOpen solver switch is a setting of
+    the whole host application); entry points call apply_miopen_workaround(), and building a trainable net without it warns."""
+    import subprocess
+    name = "MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC"
+    code = ("import os, sys, importlib; sys.path.insert(0, %r); os.environ.pop(%r, None); "
+            "cn = importlib.import_module('3dfacerecon_amd.nets.coarse_net'); assert %r not in os.environ; "
+            "assert cn.apply_miopen_workaround() == '0' and os.environ[%r] == '0'; print('ok')" % (ROOT, name, name, name))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+    cn = pkg("nets.coarse_net")
+    monkeypatch.delenv(name, raising=False)
+    with pytest.warns(RuntimeWarning, match="apply_miopen_workaround"):
+        cn.FineNet()
+    monkeypatch.setenv(name, "1")      # an explicit '1' is respected by the helper and still warned about
+    assert cn.apply_miopen_workaround() == "1"
+    with pytest.warns(RuntimeWarning):
+        cn.FineNet()
+    monkeypatch.setenv(name, "0")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        cn.FineNet()
+
+
 def test_ddp_gradient_allreduce_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

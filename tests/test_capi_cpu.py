@@ -85,9 +85,21 @@ def test_round3_entry_points_validate_before_any_hip_call():
     assert L.fr_decode_3dmm_q30(one, ctypes.c_void_p(256), nul, 1, 10, 5, 3, f, one, nul, 0, nul) == -2
     assert L.fr_decode_3dmm_q30(one, ctypes.c_void_p(256), nul, 1, 10, 600, 3, f, one, one, 1 << 20, nul) == -4
     assert L.fr_decode_3dmm_q30(one, ctypes.c_void_p(256), nul, 0, 10, 5, 3, f, one, nul, 0, nul) == 0
+    # round 5: the level count is an argument (7 / 5 / 4), validated before anything else
+    q = ctypes.c_void_p(256)
+    assert L.fr_decode_3dmm_q30_lv(one, q, nul, 1, 10, 5, 3, f, 6, one, one, 1 << 20, nul) == -1
+    assert L.fr_decode_3dmm_q30_lv(one, q, nul, 1, 10, 5, 3, f, 4, one, nul, 0, nul) == -2
+    assert L.fr_decode_3dmm_q30_lv(one, q, nul, 0, 10, 5, 3, f, 5, one, nul, 0, nul) == 0
+    qargs = lambda phases, lv=4, hand=one, qws=one, qb=1 << 20, B=1: (one, q, nul, one, one, B, 20, 2, 2, 5, 8, 8, 1, f, lv, hand,  # noqa: E731
+                                                                       3 * 32 * 4, one, one, one, one, nul, 0, qws, qb, nul, phases)
+    assert L.fr_decode_render_forward_q30(*qargs(0)) == -1 and L.fr_decode_render_forward_q30(*qargs(11, lv=3)) == -1
+    assert L.fr_decode_render_forward_q30(*qargs(11, B=0)) == 0
+    assert L.fr_decode_render_forward_q30(*qargs(11, hand=nul)) == -2
+    assert L.fr_decode_render_forward_q30(*qargs(11, qws=nul, qb=0)) == -2        # no staging workspace
     # packed backward: image size = row blocks x coefficient blocks x 1 KiB; too small a buffer; null image
     rb, sb = (3 * 53215 + 15) // 16, 13 + 2
     assert L.fr_decode_backward_basis_bytes(53215, 199, 29) == rb * sb * 1024
+    assert L.fr_decode_backward_basis_bytes(15, 9, 5) == 0 and L.fr_decode_backward_basis_bytes(16, 9, 5) > 0   # whole tiles only
     assert L.fr_decode_backward_pack_basis(one, one, 53215, 199, 29, one, 1024, nul) == -2
     assert L.fr_decode_3dmm_backward_packed(one, one, one, nul, nul, 2, 10, 5, 3, f, one, one, 1 << 30, nul) == -1
     assert L.fr_decode_3dmm_backward_packed(one, one, one, one, nul, 2, 10, 5, 3, f, one, one, 16, nul) == -2

@@ -47,6 +47,29 @@ def test_vs_f64_small(oracle, synth, gu, gv, ns, ne, B):
     _check(oracle, A, P, G)
 
 
+@pytest.mark.parametrize("gu,gv", [(2, 3), (3, 5), (4, 4)])
+def test_tiny_mesh_takes_the_reference_layout_path(oracle, synth, gu, gv):
+    """the fused (packed) backward loads sixteen floats per tile row, so a mesh of fewer than 16 vertices must
+    not reach it -- fr_decode_backward_basis_bytes answers 0, the pack / packed entry points FR_ERR_UNSUPPORTED, and the autograd
+    node falls back to the reference-layout kernels; N = 16 is the first mesh the packed path serves."""
+    from conftest import pkg
+    h = pkg("_lib")
+    L = h.lib()
+    N = gu * gv
+    A = synth.make_assets(gu, gv, 9, 5, patch=None, seed_basis=N)
+    assert (L.fr_decode_backward_basis_bytes(N, 9, 5) == 0) == (N < 16)
+    rs = np.random.RandomState(N)
+    P = _params(rs, 4, 9, 5)
+    G = rs.standard_normal((4, 3, N)).astype(np.float32)
+    _check(oracle, A, P, G)
+    net = net_mod().FaceRecNet(mesh_data=A, batch_size=4, im_size=200)
+    assert (net._basis.image_t() is None) == (N < 16)
+    if N < 16:
+        one = torch.zeros((1 << 16,), dtype=torch.uint8, device="cuda:0")
+        assert L.fr_decode_backward_pack_basis(h.ptr(net._basis.pc_shape), h.ptr(net._basis.pc_exp), N, 9, 5, h.ptr(one), 1 << 16,
+                                               None) == -4
+
+
 def test_full_size_deterministic(oracle, full_assets):
     A = full_assets
     rs = np.random.RandomState(3)

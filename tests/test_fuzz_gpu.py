@@ -121,16 +121,20 @@ def test_decode_both_arithmetics(oracle, synth, seed):
     R = oracle.rotation_matrix_batch(P[:, :3])
     net = net_mod().FaceRecNet(mesh_data=A, batch_size=B, im_size=200)
     h = pkg("_lib")
-    prev = h.decode_arith()
+    prev, prev_lv = h.decode_arith(), h.q30_levels()
+    lv = int(rs.choice([7, 5, 4]))          # digit-product levels of the Q30 leg
+    sched = int(rs.choice([0, 1, 2]))       # and its schedule (matters for the model's shape only)
     try:
-        for mode, q30 in ((1, False), (0, True)):
-            h.set_decode_arith(mode)
-            got = net.vertices_transform(torch.as_tensor(P, device="cuda:0"), R=torch.as_tensor(R, device="cuda:0"))
-            torch.cuda.synchronize()
+        for mode, q30 in ((1, False), (0, lv)):
+            h.set_decode_arith(mode, lv)
+            with h.options(FR_Q30_SCHED=sched):
+                got = net.vertices_transform(torch.as_tensor(P, device="cuda:0"), R=torch.as_tensor(R, device="cuda:0"))
+                torch.cuda.synchronize()
             want = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R, q30=q30)
-            np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg="seed %d %s" % (seed, "q30" if q30 else "f32"))
+            np.testing.assert_array_equal(got.cpu().numpy(), want,
+                                          err_msg="seed %d %s" % (seed, "q30 levels %d sched %d" % (lv, sched) if q30 else "f32"))
     finally:
-        h.set_decode_arith(prev)
+        h.set_decode_arith(prev, prev_lv)
 
 
 @pytest.mark.parametrize("seed", range(max(1, N_RENDER // 4)))

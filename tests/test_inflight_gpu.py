@@ -1,11 +1,12 @@
 """pipeline.BatchesInFlight: independent batches on their own streams, no edge between them.  Bar: whatever runs beside a
 batch, its vertices and planes are bit-identical to DecodeRenderPlan.step() on the same parameters (which
 tests/test_pipeline_gpu.py holds to the CPU oracle on all 64 full-size faces)."""
+import numpy as np
 import pytest
 import torch
 
 from conftest import pkg
-from gpu_util import net_mod
+from gpu_util import assert_render_equal, net_mod
 
 pytestmark = pytest.mark.gpu
 NAMES = ("depth", "texture_image", "normal", "tri_ind")
@@ -73,6 +74,68 @@ def test_resident_parameters_many_steps_and_a_consumer_on_the_current_stream(ful
         for g, w, n in zip(sl.outputs(), want[i], NAMES):
             assert torch.equal(g, w), "slot %d, %s" % (i, n)
         assert torch.equal(sums[i], want[i][0].clamp_min(0).sum())
+
+
+@pytest.mark.parametrize("arith", ["f32", "q30l4"])
+def test_in_flight_slots_against_the_oracle_directly(oracle, full_assets, synth, arith):
+    """the in-flight route against the CPU oracle itself, not only against the serial plan.  Two slots, eight
+    full-size faces each, six submits deep so that the batches really run beside each other; then each slot's vertices against
+    oracle.decode_3dmm (the slot's arithmetic; in-kernel rotation: <= 2 ulp and >= 99 % bit-equal, the bar of
+    tests/test_decode_gpu.py) and its four planes against oracle.render_depth on those very vertices, bit for bit."""
+    dev = torch.device("cuda:0")
+    B = 8
+    h = pkg("_lib")
+    prev, prev_lv = h.decode_arith(), h.q30_levels()
+    if arith != "f32":
+        h.set_decode_arith(h.DECODE_ARITH_Q30, int(arith[-1]))
+    try:
+        net = net_mod().FaceRecNet(mesh_data=full_assets, batch_size=B, im_size=200, device=dev)
+        fl = pkg("pipeline").BatchesInFlight(net, B, 200, 200, slots=2)
+        assert fl.slots[0].q30 == (0 if arith == "f32" else int(arith[-1]))
+        Ps = [synth.sample_params_batch(B, im_size=200, beta=0.7, seed=s) for s in (3456, 4567)]
+        for sl, P in zip(fl.slots, Ps):
+            sl.params.copy_(torch.as_tensor(P, device=dev))
+        torch.cuda.synchronize()
+        for _ in range(6):
+            fl.submit()
+        fl.synchronize()
+    finally:
+        h.set_decode_arith(prev, prev_lv)
+    A = full_assets
+    for sl, P in zip(fl.slots, Ps):
+        V = sl.vertex_proj.contiguous().cpu().numpy()
+        Vo = oracle.decode_3dmm(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=oracle.rotation_matrix_batch(P[:, :3]), q30=sl.q30)
+        a, o = V.view(np.int32).astype(np.int64), Vo.view(np.int32).astype(np.int64)
+        ulp = np.abs(np.where(a < 0, -(a & 0x7FFFFFFF), a) - np.where(o < 0, -(o & 0x7FFFFFFF), o))
+        assert ulp.max() <= 2 and (ulp == 0).mean() >= 0.99
+        want = oracle.render_depth(V, A["tri"], A["vertex"][None], 200, 200)
+        assert_render_equal(tuple(t.cpu().numpy() for t in sl.outputs()), want, "in-flight slot (%s)" % arith)
+        assert float((want[3] >= 0).mean()) > 0.2
+
+
+def test_a_bound_plan_step_orders_its_parameter_copy(full_assets, synth):
+    """DecodeRenderPlan.step(params) on a plan BOUND to a stream must copy `params` on that stream, behind
+    the current stream that produced them -- the decode otherwise reads the plan's buffer before or while the copy lands."""
+    dev = torch.device("cuda:0")
+    B = 16
+    net = net_mod().FaceRecNet(mesh_data=full_assets, batch_size=B, im_size=200, device=dev)
+    pipe = pkg("pipeline")
+    serial = pipe.DecodeRenderPlan(net, B, 200, 200)
+    st = torch.cuda.Stream(device=dev)
+    bound = pipe.DecodeRenderPlan(net, B, 200, 200, stream=st)
+    P = [torch.as_tensor(synth.sample_params_batch(B, im_size=200, beta=0.7, seed=s), device=dev) for s in range(40, 46)]
+    for p in P:
+        want = [t.clone() for t in serial.step(p)]
+        # the producer of the parameters runs on the CURRENT stream right before step(): a long-ish elementwise chain
+        q = p.clone()
+        for _ in range(20):
+            q = q * 1.0 + 0.0
+        outs = bound.step(q)
+        del q                                     # (record_stream keeps its memory until the bound stream's copy has run)
+        st.synchronize()
+        for g, w, n in zip(outs, want, NAMES):
+            assert torch.equal(g, w), n
+    del bound                                     # (__del__ drains the bound stream before the buffers are released)
 
 
 def test_a_bound_plan_refuses_capture(synth):

@@ -10,14 +10,15 @@ from conftest import pkg as pkg_mod
 pytestmark = pytest.mark.gpu
 
 
-def test_params_to_depth_q30(oracle, full_assets, synth):
-    """The same chain with the opt-in Q30 decode arithmetic: bit-exact against its own CPU spec -> oracle rasteriser, and
-    its depth against the float64 decode recorded next to the f32 chain's (a correctly rounded blend leaves only the
-    fp32 pose product's roundings)."""
+@pytest.mark.parametrize("levels", [7, 5, 4])
+def test_params_to_depth_q30(oracle, full_assets, synth, levels):
+    """The same chain with the Q30 decode arithmetic (7 / 5 / 4 digit-product levels): bit-exact against its own CPU spec ->
+    oracle rasteriser, and its depth against the float64 decode recorded next to the f32 chain's (a correctly rounded blend
+    leaves only the fp32 pose product's roundings)."""
     A = full_assets
     h = pkg_mod("_lib")
-    prev = h.decode_arith()
-    h.set_decode_arith(0)
+    prev, prev_lv = h.decode_arith(), h.q30_levels()
+    h.set_decode_arith(0, levels)
     try:
         P = synth.sample_params_batch(2, beta=0.7, seed=3456)
         R = oracle.rotation_matrix_batch(P[:, :3])
@@ -26,21 +27,21 @@ def test_params_to_depth_q30(oracle, full_assets, synth):
         outs = ops().render_depth(V, net.tri, net.vertex_code, torch.zeros((2, 200, 200, 3), device="cuda:0"))
         got = tuple(o.cpu().numpy() for o in outs)
     finally:
-        h.set_decode_arith(prev)
-    Vo = oracle.decode_3dmm_q30(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R)
+        h.set_decode_arith(prev, prev_lv)
+    Vo = oracle.decode_3dmm_q30(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R, levels=levels)
     assert_render_equal(got, oracle.render_depth(Vo, A["tri"], A["vertex"][None], 200, 200), "params->depth (q30)")
     V64 = oracle.decode_3dmm_f64(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0)
     want64 = oracle.render_depth(V64.astype(np.float32), A["tri"], A["vertex"][None], 200, 200)
     same = (want64[3] == got[3]) & (got[3] >= 0)
     d = np.abs(got[0][same].astype(np.float64) - want64[0][same].astype(np.float64))
-    report = {"decode_arith": "q30", "pixels_compared": int(same.sum()), "max_abs_ddepth": float(d.max()),
+    report = {"decode_arith": "q30", "levels": levels, "pixels_compared": int(same.sum()), "max_abs_ddepth": float(d.max()),
               "frac_within_1e-5": float((d <= 1e-5).mean()), "frac_bit_equal": float((d == 0).mean()),
               "tri_ind_disagree_frac": float((want64[3] != got[3]).mean())}
     print("params->depth vs float64 decode (q30):", report)
     try:
         import json, os
         os.makedirs("gpurun_out", exist_ok=True)
-        json.dump(report, open("gpurun_out/parity_depth_vs_f64_q30.json", "w"), indent=1)
+        json.dump(report, open("gpurun_out/parity_depth_vs_f64_q30%s.json" % ("" if levels == 7 else "l%d" % levels), "w"), indent=1)
     except OSError:
         pass
     assert report["frac_within_1e-5"] >= 0.97 and report["tri_ind_disagree_frac"] < 2e-3
@@ -215,20 +216,23 @@ def test_plan_route_full_batch64_every_face_against_the_oracle(oracle, full_asse
         assert torch.equal(g, w) and torch.equal(g2, w)
 
 
-def test_q30_plan_capture_and_replay(oracle, full_assets, synth):
+@pytest.mark.parametrize("levels", [7, 4])
+def test_q30_plan_capture_and_replay(oracle, full_assets, synth, levels):
     """with the Q30 arithmetic selected, capture() / replay() must work -- the staging buffer
-    is the plan's own, nothing is allocated at launch time -- and the replayed decode is the Q30 spec's, bit for bit."""
+    is the plan's own, nothing is allocated at launch time -- and the replayed decode is the Q30 spec's, bit for bit.
+    Round 5: the plan runs fr_decode_render_forward_q30 (pitched hand-off rows, one C call) with the level count of the
+    moment it was built."""
     pipe = __import__("importlib").import_module("3dfacerecon_amd.pipeline")
     h = pkg_mod("_lib")
     A = full_assets
-    prev = h.decode_arith()
-    h.set_decode_arith(h.DECODE_ARITH_Q30)
+    prev, prev_lv = h.decode_arith(), h.q30_levels()
+    h.set_decode_arith(h.DECODE_ARITH_Q30, levels)
     try:
         net = net_mod().FaceRecNet(mesh_data=A, batch_size=3, im_size=200)
         assert net._basis._qimage is None                    # nothing of Q30 exists before it is used
         P = synth.sample_params_batch(3, beta=0.7, seed=21)
         plan = pipe.DecodeRenderPlan(net, 3, 200, 200)
-        assert plan.q30 and net._basis._qimage is not None
+        assert plan.q30 == levels and net._basis._qimage is not None and plan.pitch % 32 == 0
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):                        # capture on a stream the plan has never launched on
             plan.params.copy_(torch.as_tensor(P, device="cuda:0"))
@@ -238,10 +242,10 @@ def test_q30_plan_capture_and_replay(oracle, full_assets, synth):
         side.synchronize()
         torch.cuda.synchronize()
     finally:
-        h.set_decode_arith(prev)
+        h.set_decode_arith(prev, prev_lv)
     # in-kernel rotation: compare through the host-R route for the bit-exact leg
     R = oracle.rotation_matrix_batch(P[:, :3])
-    Vo = oracle.decode_3dmm_q30(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R)
+    Vo = oracle.decode_3dmm_q30(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R, levels=levels)
     a, o = Vq.cpu().numpy().view(np.int32).astype(np.int64), Vo.view(np.int32).astype(np.int64)
     ulp = np.abs(np.where(a < 0, -(a & 0x7FFFFFFF), a) - np.where(o < 0, -(o & 0x7FFFFFFF), o))
     assert ulp.max() <= 2 and (ulp == 0).mean() >= 0.99

@@ -21,7 +21,7 @@ HF="--offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17"
 [ -f tools/libemit_probe.so ] || leg build_emit_probe hipcc $HF -mllvm -amdgpu-atomic-optimizer-strategy=None -fPIC -shared -o tools/libemit_probe.so tools/emit_probe.hip
 [ -x tools/pmc_calib ] || leg build_pmc_calib hipcc --offload-arch=gfx950 -O3 -o tools/pmc_calib tools/pmc_calib.hip
 # ---- parity, smoke, bench -------------------------------------------------------------------------------------------------
-leg pytest_gpu bash -c "python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -12 > $O/pytest_gpu.log; grep -q ' passed' $O/pytest_gpu.log && ! grep -q failed $O/pytest_gpu.log"
+leg pytest_gpu bash -c "set -o pipefail; python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -12 > $O/pytest_gpu.log"   # (pytest's own exit status: collection / fixture errors fail the leg too)
 leg smoke bash -c "python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1"
 leg bench bash -c "python bench.py > $O/bench.json 2> $O/bench.err"
 leg bench_k20 bash -c "python bench.py --steps 20 --warmup 5 --cpu-faces 0 > $O/bench_k20.json 2>> $O/bench.err"
