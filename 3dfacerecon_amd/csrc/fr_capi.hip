@@ -402,4 +402,18 @@ int fr_decode_3dmm_backward_packed(const float* grad_vertex_proj, const float* p
                                      im_size, grad_params, workspace, (hipStream_t)hip_stream, n_shape + n_exp > 0 ? packed_t : nullptr);
 }
 
+int fr_decode_3dmm_backward_packed_mu(const float* grad_vertex_proj, const float* params, const float* mu, const void* packed_t,
+                                      const float* R_override, int B, int N, int n_shape, int n_exp, float im_size,
+                                      float* grad_params, void* workspace, size_t ws_bytes, void* hip_stream) {
+    if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0) return FR_ERR_INVALID_ARG;
+    if (fr_decode_backward_basis_bytes(N, n_shape, n_exp) == 0) return FR_ERR_UNSUPPORTED;   // what the fused kernel does not serve
+    if (B == 0) return FR_OK;
+    if (!grad_params || !params || !grad_vertex_proj || !mu || !packed_t) return FR_ERR_INVALID_ARG;
+    if (((uintptr_t)packed_t & 15) != 0 || ((uintptr_t)mu & 15) != 0) return FR_ERR_INVALID_ARG;
+    if (ws_bytes < fr_decode_backward_workspace_bytes(B, N, n_shape, n_exp)) return FR_ERR_WORKSPACE;
+    if (!workspace || ((uintptr_t)workspace & 15)) return FR_ERR_WORKSPACE;
+    return fr_launch_decode_backward(grad_vertex_proj, params, nullptr, nullptr, nullptr, R_override, B, N, n_shape, n_exp,
+                                     im_size, grad_params, workspace, (hipStream_t)hip_stream, packed_t, mu);
+}
+
 }  // extern "C"

@@ -85,12 +85,15 @@ __device__ __forceinline__ bool point_in_tri(const TriSetup& s, int x, int y) {
 // the entry points may be called from several host threads (the header says so); two threads racing here both set the same
 // attribute to the same value and both store 1 -- idempotent, and now also free of a data race in the C++ sense.
 typedef std::atomic<unsigned char> fr_lds_flags_t;
-inline hipError_t fr_allow_full_lds(const void* kernel, fr_lds_flags_t* done /*[64], zero-initialised (static storage)*/) {
+// `dynamic_max`: the dynamic part's ceiling -- 160 KiB for kernels without static LDS arrays, less for a kernel that also declares
+// static ones (the attribute is refused when static + dynamic exceed the CU's 160 KiB).
+inline hipError_t fr_allow_full_lds(const void* kernel, fr_lds_flags_t* done /*[64], zero-initialised (static storage)*/,
+                                    int dynamic_max = 160 * 1024) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
-    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dynamic_max);
     if (e == hipSuccess && dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
     return e;
 }
@@ -164,7 +167,7 @@ size_t fr_decode_backward_workspace_impl(int N, int ns, int ne);
 int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
                               const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N, int ns,
                               int ne, float im_size, float* grad_params, void* workspace, hipStream_t stream,
-                              const void* packed_t = nullptr);
+                              const void* packed_t = nullptr, const float* mu = nullptr);
 size_t fr_decode_backward_basis_bytes_impl(int N, int ns, int ne);
 int fr_launch_decode_backward_pack(const float* pc_shape, const float* pc_exp, int N, int ns, int ne, void* packed_t,
                                    hipStream_t stream);

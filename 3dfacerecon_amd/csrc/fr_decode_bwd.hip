@@ -53,6 +53,12 @@ struct BwdArgs {
                              // vertex groups of 16 in all / per workgroup
     int exp_slot0;           // first coefficient slot of the expression basis in the slabs
     int nslots;              // coefficient slots per partial slab (64 per wave of the GEMM workgroup)
+    const float* mu;         // [3N] mean shape, or null.  Non-null (fr_decode_3dmm_backward_packed_mu): d f is formed WITHOUT the
+                             // forward output -- sum_p (R v_p) . dq = sum_p v_p . dv_p / f with v = mu + S alpha + E beta, i.e.
+                             // d f = (sum_p mu_p . dv_p + alpha . d alpha + beta . d beta) / f: the fused kernel reads 0.64 MB of mu
+                             // (L2-resident) instead of 41 MB of vertex_proj -- which buys MEMORY (the forward output need not be
+                             // kept for the backward), not time: 71.3 vs 71.1 us at 64 faces, 56.3 vs 53.2 at 32; each workgroup adds the parameters' dot product with
+                             // ITS partial coefficient gradients to its pose partial (linear: the partials add up to the whole)
 };
 
 __device__ __forceinline__ void bwd_rotation(const BwdArgs& a, int b, float* R9) {
@@ -335,6 +341,7 @@ __global__ __launch_bounds__(CB == 2 ? 512 : 256) void bwd_fused_kernel(BwdArgs 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nd = FR_N_POSE + a.ns + a.ne;
     const int N = a.N;
+    const bool muf = a.mu != nullptr;   // (uniform) d f from mu . dv: the tile's second operand is mu, not vertex_proj
     if (tid < 64) {
         float m[13];
 #pragma unroll
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(CB == 2 ? 512 : 256) void bwd_fused_kernel(BwdArgs 
     for (int i = 0; i < 13; i++) m[i] = Mt[sb_][i];
     const int bc = min(sb_, a.nbatch - 1);   // (dead columns load a live column's tile and discard it)
     const float* gx = a.g + (size_t)(a.b0 + bc) * 3 * N + 4 * q;
-    const float* vx = a.vproj + (size_t)(a.b0 + bc) * 3 * N + 4 * q;
+    const float* vx = muf ? a.mu + 4 * q : a.vproj + (size_t)(a.b0 + bc) * 3 * N + 4 * q;
     // MFMA role: this wave's CB 16-coefficient blocks
     const int kq = lane >> 4, jn = lane & 15;
     const int sbt = a.sbt;
@@ -426,31 +433,45 @@ __global__ __launch_bounds__(CB == 2 ? 512 : 256) void bwd_fused_kernel(BwdArgs 
                 ok = false;   // (clamped group: taken by the slow path below)
             }
             const float dq0 = ok ? g0 : 0.f, dq1 = ok ? -g1 : 0.f, dq2 = ok ? g2 : 0.f;
-            const float q0 = v0 - m[9], q1 = ((a.im_size - 1.0f) - v1) - m[10], q2 = v2 - m[11];
-            const float fs = ok ? __builtin_fmaf(q2, dq2, __builtin_fmaf(q1, dq1, q0 * dq0)) : 0.f;
-            ps0 += dq0; ps1 += dq1; ps2 += dq2; ps3 += fs;
             // (a slot without a vertex or a column without a face is exactly zero -- not 0 * m, which an infinite f would turn
             // into a NaN that the zero-padded basis rows then spread over the whole sum)
 #pragma unroll
             for (int c = 0; c < 3; c++)
                 dvr[c][r] = ok ? __builtin_fmaf(m[6 + c], dq2, __builtin_fmaf(m[3 + c], dq1, m[c] * dq0)) : 0.f;
+            float fs;
+            if (muf) {   // mu_p . dv_p (v0..v2 hold mu's x / y / z of this vertex)
+                fs = ok ? __builtin_fmaf(v2, dvr[2][r], __builtin_fmaf(v1, dvr[1][r], v0 * dvr[0][r])) : 0.f;
+            } else {
+                const float q0 = v0 - m[9], q1 = ((a.im_size - 1.0f) - v1) - m[10], q2 = v2 - m[11];
+                fs = ok ? __builtin_fmaf(q2, dq2, __builtin_fmaf(q1, dq1, q0 * dq0)) : 0.f;
+            }
+            ps0 += dq0; ps1 += dq1; ps2 += dq2; ps3 += fs;
         }
         if (shift != 0 && stager) {   // the one clamped group of the launch: guarded scalar loads (drains the wave's loads once)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const long long pvx = 16 * grp + 4 * q + r;
                 float dq0 = 0.f, dq1 = 0.f, dq2 = 0.f, fs = 0.f;
-                if (blive && pvx < N) {
+                const bool okx = blive && pvx < N;
+                float vv[3] = {0.f, 0.f, 0.f};
+                if (okx) {
                     const float* gb = a.g + (size_t)(a.b0 + bc) * 3 * N + pvx;
-                    const float* vb = a.vproj + (size_t)(a.b0 + bc) * 3 * N + pvx;
+                    const float* vb = muf ? a.mu + pvx : a.vproj + (size_t)(a.b0 + bc) * 3 * N + pvx;
                     dq0 = gb[0]; dq1 = -gb[N]; dq2 = gb[2 * (size_t)N];
-                    const float q0 = vb[0] - m[9], q1 = ((a.im_size - 1.0f) - vb[N]) - m[10], q2 = vb[2 * (size_t)N] - m[11];
-                    fs = __builtin_fmaf(q2, dq2, __builtin_fmaf(q1, dq1, q0 * dq0));
+                    vv[0] = vb[0]; vv[1] = vb[N]; vv[2] = vb[2 * (size_t)N];
                 }
-                ps0 += dq0; ps1 += dq1; ps2 += dq2; ps3 += fs;
 #pragma unroll
                 for (int c = 0; c < 3; c++)
-                    dvr[c][r] = (blive && pvx < N) ? __builtin_fmaf(m[6 + c], dq2, __builtin_fmaf(m[3 + c], dq1, m[c] * dq0)) : 0.f;
+                    dvr[c][r] = okx ? __builtin_fmaf(m[6 + c], dq2, __builtin_fmaf(m[3 + c], dq1, m[c] * dq0)) : 0.f;
+                if (okx) {
+                    if (muf) {
+                        fs = __builtin_fmaf(vv[2], dvr[2][r], __builtin_fmaf(vv[1], dvr[1][r], vv[0] * dvr[0][r]));
+                    } else {
+                        const float q0 = vv[0] - m[9], q1 = ((a.im_size - 1.0f) - vv[1]) - m[10], q2 = vv[2] - m[11];
+                        fs = __builtin_fmaf(q2, dq2, __builtin_fmaf(q1, dq1, q0 * dq0));
+                    }
+                }
+                ps0 += dq0; ps1 += dq1; ps2 += dq2; ps3 += fs;
             }
         }
         if (stager) {
@@ -523,6 +544,41 @@ __global__ __launch_bounds__(CB == 2 ? 512 : 256) void bwd_fused_kernel(BwdArgs 
                 for (int ii = 0; ii < CB; ii++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[dd][c][ii]));
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(tg[0]), "+v"(tg[1]), "+v"(tg[2]), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]));
     }
+    // mu form of d f: this workgroup's share of alpha . d alpha + beta . d beta -- the parameters against the PARTIAL coefficient
+    // gradients it has just accumulated (the dot product is linear, so the shares of all workgroups add up to the whole; no
+    // third launch, nothing read back).  Lane (kq, jn) of wave w holds slots 16 (CB w + i) + 4 kq + rg of columns 16 mb + jn:
+    // its products go to xp[w][kq][column], and the column's 4 x waves partials are added in a fixed order below.
+    float* xp = reinterpret_cast<float*>(&dvL[0][0][0][0]);   // (the dv buffers are dead: every wave is past its last MFMA)
+    const int nwaves = (int)(blockDim.x >> 6);
+    if (muf) {
+        __syncthreads();
+        float xd[NB];
+#pragma unroll
+        for (int mb = 0; mb < NB; mb++) xd[mb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < CB; i++)
+            if (i < nsb) {
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    const int slot = 16 * (CB * wave + i) + 4 * kq + rg;
+                    // slot -> parameter: shape slots [0, ns), expression slots from 16 sbs; padding slots carry no parameter.
+                    // (Gathered here, once per workgroup.  Staging the parameters by slot in LDS at kernel start instead --
+                    // 62 KB, conflict-free reads -- measured 1 / 4 / 7 us SLOWER at 64 / 32 / 16 faces: tools/bwd_ab_probe.py.)
+                    int k = -1;
+                    if (slot < 16 * a.sbs) { if (slot < a.ns) k = slot; }
+                    else if (slot - 16 * a.sbs < a.ne) k = a.ns + slot - 16 * a.sbs;
+#pragma unroll
+                    for (int mb = 0; mb < NB; mb++) {
+                        const int col = 16 * mb + jn;
+                        const float x = (k >= 0 && col < a.nbatch) ? a.params[(size_t)(a.b0 + col) * nd + FR_N_POSE + k] : 0.f;
+                        xd[mb] = __builtin_fmaf(x, acc[i][mb][rg], xd[mb]);
+                    }
+                }
+            }
+#pragma unroll
+        for (int mb = 0; mb < 4; mb++) xp[(wave * 4 + kq) * 64 + 16 * mb + jn] = mb < NB ? xd[mb < NB ? mb : 0] : 0.f;
+        __syncthreads();
+    }
     // pose partial sums: the four vertex quads of a column are the four lanes of a DPP quad -- (q0 + q1) + (q2 + q3), fixed
     if (stager) {
 #define FR_QUAD_SUM(x)                                                                                                         \
@@ -531,6 +587,13 @@ __global__ __launch_bounds__(CB == 2 ? 512 : 256) void bwd_fused_kernel(BwdArgs 
         FR_QUAD_SUM(ps0) FR_QUAD_SUM(ps1) FR_QUAD_SUM(ps2) FR_QUAD_SUM(ps3)
 #undef FR_QUAD_SUM
         if (q == 0) {
+            if (muf) {   // + this workgroup's share of alpha . d alpha + beta . d beta, waves ascending, kq ascending
+                float t = 0.f;
+                for (int w = 0; w < nwaves; w++)
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) t += xp[(w * 4 + kk) * 64 + sb_];
+                ps3 += t;
+            }
             float* pp = a.pose_part + ((size_t)blockIdx.x * 64 + sb_) * 4;
             pp[0] = ps0; pp[1] = ps1; pp[2] = ps2; pp[3] = ps3 * m[12];
         }
@@ -707,7 +770,7 @@ int fr_launch_decode_backward_pack(const float* pc_shape, const float* pc_exp, i
 int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params, const float* vertex_proj,
                               const float* pc_shape, const float* pc_exp, const float* R_override, int B, int N, int ns,
                               int ne, float im_size, float* grad_params, void* workspace, hipStream_t stream,
-                              const void* packed_t) {
+                              const void* packed_t, const float* mu) {
     using namespace fr;
     if (B == 0) return FR_OK;
     const int nd = FR_N_POSE + ns + ne;
@@ -732,6 +795,7 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
     a.sbt = g.sbt; a.sbs = g.sbs;
     a.rbt = packed ? g.ngroups : g.rbt;
     a.rb_per_block = packed ? g.groups_per_block : g.rb_per_block;
+    a.mu = packed ? mu : nullptr;   // (the mu form of d f exists on the packed path only)
     a.exp_slot0 = packed ? 16 * g.sbs : bw_ns4(ns);
     a.nslots = packed ? 16 * g.cb_p * g.block_waves_p : 64 * bw_waves(ns, ne);
     for (int b0 = 0; b0 < B; b0 += 64) {
@@ -748,16 +812,18 @@ int fr_launch_decode_backward(const float* grad_vertex_proj, const float* params
                 }
             }
             const dim3 gb(g.block_waves_p * 64);
+#define FR_BWD_LAUNCH1(NBV, CBV) hipLaunchKernelGGL((bwd_fused_kernel<NBV, CBV>), dim3(a.gemm_blocks), gb, 0, stream, a);
 #define FR_BWD_LAUNCH(NBV)                                                                                            \
     {                                                                                                                 \
-        if (g.cb_p == 2) hipLaunchKernelGGL((bwd_fused_kernel<NBV, 2>), dim3(a.gemm_blocks), gb, 0, stream, a);       \
-        else hipLaunchKernelGGL((bwd_fused_kernel<NBV, 4>), dim3(a.gemm_blocks), gb, 0, stream, a);                   \
+        if (g.cb_p == 2) FR_BWD_LAUNCH1(NBV, 2)                                                                       \
+        else FR_BWD_LAUNCH1(NBV, 4)                                                                                   \
     }
             if (nbt == 1) FR_BWD_LAUNCH(1)
             else if (nbt == 2) FR_BWD_LAUNCH(2)
             else if (nbt == 3) FR_BWD_LAUNCH(3)
             else FR_BWD_LAUNCH(4)
 #undef FR_BWD_LAUNCH
+#undef FR_BWD_LAUNCH1
         } else {
             hipLaunchKernelGGL(bwd_prepass_kernel, dim3(g.pre_blocks), dim3(256), 0, stream, a);
             if (waves > 0) {

@@ -70,6 +70,9 @@ class PackedBasis:
         self._t_owner = None   # another PackedBasis of the SAME pc_shape / pc_exp whose image_t this one shares (the K-major
                                # image does not contain mu, so a mu = 0 twin needs no second 153 MB copy)
         self.q30_ws_bytes = L.fr_decode_q30_workspace_bytes(ndim_shape, ndim_exp)
+        self._packed_ok = None
+        self.backward_from_mu = False   # True: the autograd node's backward does not keep the forward's output (see _Decode3DMM)
+        self._bwd_ws = {}      # decode-backward workspaces by (device, stream, bytes): backward_workspace()
 
     def image_t(self):
         """The basis packed for the decode backward (fr_decode_backward_pack_basis), built on first use: callers that never
@@ -90,6 +93,33 @@ class PackedBasis:
             _publish(self.device)
             self._image_t = buf
         return self._image_t
+
+    def backward_packed_ok(self):
+        """True when the fused backward (packed image, d f from mu) serves this basis / mesh."""
+        if self._t_owner is not None:
+            return self._t_owner.backward_packed_ok()
+        if self._packed_ok is None:
+            self._packed_ok = _host().lib().fr_decode_backward_basis_bytes(self.nvert, self.ndim_shape, self.ndim_exp) > 0
+        return self._packed_ok
+
+    def backward_workspace(self, B, dev):
+        """(bytes, buffer) of the decode backward's workspace for B faces on torch's current stream of `dev`.  The buffer is kept
+        per (stream, size) -- launches on one stream are ordered, so consecutive backwards may share it; at most four are held
+        (least recently used dropped); under graph capture a fresh one is taken (a captured launch must not point at a buffer
+        the cache may later replace).  The size query and the allocation used to be paid per call: with the kernels at ~70 us
+        the autograd route was host-bound below 64 faces (profiles/round4_bwd_probe.log)."""
+        L = _host().lib()
+        nws = L.fr_decode_backward_workspace_bytes(B, self.nvert, self.ndim_shape, self.ndim_exp)
+        if torch.cuda.is_current_stream_capturing():
+            return nws, torch.empty((max(nws, 16),), dtype=torch.uint8, device=dev)
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, nws)
+        buf = self._bwd_ws.pop(key, None)
+        if buf is None:
+            buf = torch.empty((max(nws, 16),), dtype=torch.uint8, device=dev)
+        self._bwd_ws[key] = buf               # (re-inserted last: most recently used)
+        while len(self._bwd_ws) > 4:
+            self._bwd_ws.pop(next(iter(self._bwd_ws)))
+        return nws, buf
 
     def use_q30(self):
         """True when the Q30 entry point serves this call: selected AND the shape is covered (else the f32 chain)."""
@@ -144,7 +174,17 @@ class _Decode3DMM(torch.autograd.Function):
         ctx.net = net
         ctx.basis = basis
         ctx.im_size = im_size
-        ctx.save_for_backward(params, out, R if R is not None else params.new_empty(0))
+        # The fused backward has two forms of d f.  Default: from the forward's output (fr_decode_3dmm_backward_packed; `out` stays
+        # alive for the backward -- 41 MB per 64-face decode).  `basis.backward_from_mu = True` selects the form that needs no
+        # forward output (fr_decode_3dmm_backward_packed_mu: d f from mu and the coefficient gradients) -- a MEMORY saving, not a
+        # faster kernel (same time at 64 faces, 3 us more at 32: profiles/round5_probes/r5d).  Bases / meshes the fused kernel
+        # does not serve take the reference-layout entry point, which needs `out`.
+        ctx.packed = basis.backward_packed_ok()
+        ctx.from_mu = ctx.packed and bool(getattr(basis, "backward_from_mu", False))
+        if ctx.from_mu:
+            ctx.save_for_backward(params, R if R is not None else params.new_empty(0))
+        else:
+            ctx.save_for_backward(params, R if R is not None else params.new_empty(0), out)
         ctx.has_R = R is not None
         return out
 
@@ -152,27 +192,30 @@ class _Decode3DMM(torch.autograd.Function):
     def backward(ctx, grad_out):
         h = _host()
         net = ctx.net
-        params, out, R = ctx.saved_tensors
+        basis = ctx.basis
+        params, R = ctx.saved_tensors[0], ctx.saved_tensors[1]
         B = int(params.shape[0])
         g = h.require_gpu_f32(grad_out, "grad_vertex_proj")
         gp = torch.empty_like(params)
         L = h.lib()
-        with torch.cuda.device(params.device):
-            nws = L.fr_decode_backward_workspace_bytes(B, net.nvert, net.ndim_shape, net.ndim_exp)
-            ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=params.device)
-            # (the fused kernel streams the packed image: built once per basis, at the first backward; bases beyond 256
-            # coefficients -- not the model's -- take the reference-layout entry point)
-            img = ctx.basis.image_t()
-            if img is not None:
-                rc = L.fr_decode_3dmm_backward_packed(h.ptr(g), h.ptr(params), h.ptr(out), h.ptr(img),
-                                                      h.ptr(R) if ctx.has_R else None, B, net.nvert, net.ndim_shape,
-                                                      net.ndim_exp, ctx.im_size, h.ptr(gp), h.ptr(ws), nws,
-                                                      h.stream_ptr(params.device))
-            else:
-                rc = L.fr_decode_3dmm_backward(h.ptr(g), h.ptr(params), h.ptr(out), h.ptr(ctx.basis.pc_shape),
-                                               h.ptr(ctx.basis.pc_exp), h.ptr(R) if ctx.has_R else None, B, net.nvert,
-                                               net.ndim_shape, net.ndim_exp, ctx.im_size, h.ptr(gp), h.ptr(ws), nws,
-                                               h.stream_ptr(params.device))
+        dev = params.device
+        with torch.cuda.device(dev):
+            nws, ws = basis.backward_workspace(B, dev)
+            Rp = h.ptr(R) if ctx.has_R else None
+            if ctx.from_mu:
+                rc = L.fr_decode_3dmm_backward_packed_mu(h.ptr(g), h.ptr(params), h.ptr(basis.mu), h.ptr(basis.image_t()), Rp, B,
+                                                         net.nvert, net.ndim_shape, net.ndim_exp, ctx.im_size, h.ptr(gp),
+                                                         h.ptr(ws), nws, h.stream_ptr(dev))
+            elif ctx.packed:
+                # (the fused kernel streams the packed image: built once per basis, at the first backward)
+                rc = L.fr_decode_3dmm_backward_packed(h.ptr(g), h.ptr(params), h.ptr(ctx.saved_tensors[2]), h.ptr(basis.image_t()),
+                                                      Rp, B, net.nvert, net.ndim_shape, net.ndim_exp, ctx.im_size, h.ptr(gp),
+                                                      h.ptr(ws), nws, h.stream_ptr(dev))
+            else:   # more than 256 coefficients or fewer than 16 vertices (not the model's): reference-layout entry point
+                out = ctx.saved_tensors[2]
+                rc = L.fr_decode_3dmm_backward(h.ptr(g), h.ptr(params), h.ptr(out), h.ptr(basis.pc_shape),
+                                               h.ptr(basis.pc_exp), Rp, B, net.nvert, net.ndim_shape, net.ndim_exp,
+                                               ctx.im_size, h.ptr(gp), h.ptr(ws), nws, h.stream_ptr(dev))
         h.check(rc, "fr_decode_3dmm_backward")
         return gp, None, None, None, None
 

@@ -177,6 +177,43 @@ class DecodeRenderPlan:
             pass
 
 
+class GraphedSteps:
+    """R consecutive batches captured into ONE hipGraph: R DecodeRenderPlans (each its own parameters, vertex buffer, workspace
+    and output planes) whose 3 R launches are replayed with a single hipGraphLaunch.  Why: a replay is followed by a ~9 us
+    bubble before the next replay's first kernel starts (hipGraphLaunch is not pipelined with the previous graph's tail on this
+    runtime: profiles/round4_probes/r4h), which makes a one-step graph slower than three eager launches; with R steps per graph
+    the bubble is paid once per R batches.  `replay(params_list)` copies up to R parameter sets and replays; `plans[i].outputs()`
+    are batch i's planes."""
+
+    def __init__(self, net, batch, steps, height=None, width=None, texture=None):
+        if int(steps) < 1:
+            raise ValueError("steps must be >= 1")
+        self.device = net.device
+        self.plans = [DecodeRenderPlan(net, batch, height, width, texture) for _ in range(int(steps))]
+        self._graph = None
+
+    def capture(self):
+        with torch.cuda.device(self.device):
+            for p in self.plans:
+                p.step()     # warm-up launches outside the capture
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for p in self.plans:
+                    p._run(11)
+        self._graph = g
+        return g
+
+    def replay(self, params_list=None):
+        if self._graph is None:
+            self.capture()
+        if params_list is not None:
+            for p, prm in zip(self.plans, params_list):
+                p._take_params(prm)
+        self._graph.replay()
+        return [p.outputs() for p in self.plans]
+
+
 class BatchesInFlight:
     """S (default two) independent batches in flight: S DecodeRenderPlans -- each with its own parameters, vertex buffer,
     workspace and output planes -- each bound to its own HIP stream, with NO edge between the streams.  `submit()` sends the

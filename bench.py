@@ -556,7 +556,7 @@ def main():
         emit_ms = sum(e[1].elapsed_time(e[2]) for e in serial_ev) / len(serial_ev)
         resolve_ms = sum(e[2].elapsed_time(e[3]) for e in serial_ev) / len(serial_ev)
 
-    graph_fps = None
+    graph_fps = graph_multi = None
     if args.graph:   # (the serial plan: three kernel nodes per replay)
         serial_plan.capture()
         for _ in range(Wm):
@@ -567,6 +567,39 @@ def main():
             serial_plan.replay()
         torch.cuda.synchronize(dev)
         graph_fps = B * K / (time.perf_counter() - g0)
+        # ... and R batches per graph (pipeline.GraphedSteps): the replay-to-replay bubble paid once per R batches
+        graph_multi = {}
+        for Rg in (4, 8):
+            gs = pipe.GraphedSteps(net, B, Rg, H, W)
+            for i, p in enumerate(gs.plans):
+                p.params.copy_(torch.as_tensor(slot_params[i % len(slot_params)], device=dev))
+            gs.capture()
+            nrep = max(1, K // Rg)
+            for _ in range(max(1, Wm // Rg)):
+                gs.replay()
+            torch.cuda.synchronize(dev)
+            g0 = time.perf_counter()
+            for _ in range(nrep):
+                gs.replay()
+            torch.cuda.synchronize(dev)
+            dtg = time.perf_counter() - g0
+            same = all(torch.equal(a, b) for a, b in zip(gs.plans[0].outputs(), serial_plan.outputs()))
+            # the same R plans stepped EAGERLY in turn (no graph): separates what the graph costs from what R sets of buffers
+            # cycling through the 256 MiB Infinity Cache cost (the serial plan re-uses ONE set)
+            for _ in range(max(1, Wm // Rg)):
+                for p in gs.plans:
+                    p.step()
+            torch.cuda.synchronize(dev)
+            g0 = time.perf_counter()
+            for _ in range(nrep):
+                for p in gs.plans:
+                    p.step()
+            torch.cuda.synchronize(dev)
+            dte = time.perf_counter() - g0
+            graph_multi["steps_per_graph_%d" % Rg] = {"faces_per_s": B * Rg * nrep / dtg, "us_per_batch": 1e6 * dtg / (Rg * nrep),
+                                                      "same_plans_stepped_eagerly_us_per_batch": 1e6 * dte / (Rg * nrep),
+                                                      "planes_identical_to_the_serial_plan": bool(same)}
+            del gs
 
     if rank == 0:
         N, T, Kc = net.nvert, int(net.tri.shape[1]), net.ndim_shape + net.ndim_exp
@@ -777,6 +810,10 @@ def main():
                 "source": "profiles/round3_strong_scaling_shards.json (serial plan, one MI355X running a rank's shard)"}
         if graph_fps is not None:
             out["graph_replay_faces_per_s"] = graph_fps
+            out["graph_replay"] = {"one_step_per_graph_faces_per_s": graph_fps, "R_steps_per_graph": graph_multi,
+                                   "what": "hipGraph replays of the serial plan's three launches; R steps per graph = "
+                                           "pipeline.GraphedSteps (R plans, one hipGraphLaunch per R batches): the ~9 us bubble "
+                                           "between two replays (profiles/round4_probes/r4h) is paid once per R batches"}
         if args.cpu_faces > 0 and world == 1:
             cb = cpu_baseline(assets, params_np, args.cpu_faces, H, W, synth)
             out["cpu_baseline"] = cb

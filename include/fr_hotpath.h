@@ -278,6 +278,21 @@ int fr_decode_3dmm_backward_packed(const float* grad_vertex_proj, const float* p
                                    const void* packed_t, const float* R_override, int B, int N, int n_shape, int n_exp,
                                    float im_size, float* grad_params, void* workspace, size_t ws_bytes, void* hip_stream);
 
+/* The same fused backward WITHOUT the forward output (round 5).  d f = sum_p (R v_p) . dq needs the un-projected vertices; the
+ * entry points above recover R v_p from vertex_proj ((q - t3d) / f: 41 MB more to read per 64 faces, and the caller must keep
+ * the forward's output alive for the backward).  With v = mu + S alpha + E beta and dv = (f R)^T dq,
+ *     sum_p (R v_p) . dq  =  sum_p v_p . dv_p / f  =  ( sum_p mu_p . dv_p  +  alpha . d alpha  +  beta . d beta ) / f,
+ * whose first term the fused kernel forms from the 0.64 MB of mu beside the dv rows it builds anyway and whose other two are dot
+ * products of the parameters with the coefficient gradients: linear, so every workgroup adds the product with ITS partial
+ * gradients to its partial of d f and the fixed-order reduction sums them like every other output -- two launches, as before.
+ * What it buys is MEMORY, not time: measured in one process (tools/bwd_ab_probe.py) 71.3 against 71.1 us per backward at 64 faces
+ * and 56.3 against 53.2 at 32 -- the 41 MB of vertex_proj stream in for free beside the 153 MB of basis.
+ * mu [3N] in the reference layout (16-byte aligned); every other output as fr_decode_3dmm_backward_packed; d f := 0 at f == 0 as
+ * there; deterministic.  The three entry points agree to rounding.  FR_ERR_UNSUPPORTED where fr_decode_backward_basis_bytes is 0. */
+int fr_decode_3dmm_backward_packed_mu(const float* grad_vertex_proj, const float* params, const float* mu, const void* packed_t,
+                                      const float* R_override, int B, int N, int n_shape, int n_exp, float im_size,
+                                      float* grad_params, void* workspace, size_t ws_bytes, void* hip_stream);
+
 /* ---- test hook ---------------------------------------------------------------------------------------------
  * The screen-bin geometry the forward launcher chooses for a shape (no GPU needed): out = {rows per strip, strips,
  * triangle segments, 1 if the binned path covers the shape else 0 (the strip-scan fallback runs)}.  rows_override > 0

@@ -103,6 +103,11 @@ def test_round3_entry_points_validate_before_any_hip_call():
     assert L.fr_decode_backward_pack_basis(one, one, 53215, 199, 29, one, 1024, nul) == -2
     assert L.fr_decode_3dmm_backward_packed(one, one, one, nul, nul, 2, 10, 5, 3, f, one, one, 1 << 30, nul) == -1
     assert L.fr_decode_3dmm_backward_packed(one, one, one, one, nul, 2, 10, 5, 3, f, one, one, 16, nul) == -2
+    # ... and its mu form: unsupported where the fused kernel is (N < 16 here), null mu, small workspace
+    assert L.fr_decode_3dmm_backward_packed_mu(one, one, one, one, nul, 2, 10, 5, 3, f, one, one, 1 << 30, nul) == -4
+    assert L.fr_decode_3dmm_backward_packed_mu(one, one, nul, one, nul, 2, 64, 5, 3, f, one, one, 1 << 30, nul) == -1
+    assert L.fr_decode_3dmm_backward_packed_mu(one, one, one, one, nul, 2, 64, 5, 3, f, one, one, 16, nul) == -2
+    assert L.fr_decode_3dmm_backward_packed_mu(one, one, one, one, nul, 0, 64, 5, 3, f, one, one, 16, nul) == 0
 
 
 def test_options_read_the_environment_once_and_never_on_the_launch_path(monkeypatch):

@@ -21,8 +21,9 @@ def _params(rs, B, ns, ne):
     return P
 
 
-def _check(oracle, A, P, G, tol=2e-5):
+def _check(oracle, A, P, G, tol=2e-5, from_mu=False):
     net = net_mod().FaceRecNet(mesh_data=A, batch_size=P.shape[0], im_size=200)
+    net._basis.backward_from_mu = from_mu      # the autograd node's form of d f (nets/network.py::_Decode3DMM)
     p = torch.as_tensor(P, device="cuda:0").requires_grad_(True)
     V = net.vertices_transform(p)
     V.backward(torch.as_tensor(G, device="cuda:0"))
@@ -44,7 +45,11 @@ def test_vs_f64_small(oracle, synth, gu, gv, ns, ne, B):
     rs = np.random.RandomState(B)
     P = _params(rs, B, ns, ne)
     G = rs.standard_normal((B, 3, gu * gv)).astype(np.float32)
-    _check(oracle, A, P, G)
+    a = _check(oracle, A, P, G)
+    b = _check(oracle, A, P, G, from_mu=True)      # no forward output kept for the backward: the same gradient, d f to rounding
+    keep = np.ones(a.shape[1], bool)
+    keep[6] = False
+    np.testing.assert_array_equal(a[:, keep], b[:, keep])
 
 
 @pytest.mark.parametrize("gu,gv", [(2, 3), (3, 5), (4, 4)])
@@ -125,8 +130,9 @@ def test_zero_focal_column(oracle, synth):
 
 
 def test_packed_and_reference_layout_entry_points(oracle, synth):
-    """fr_decode_3dmm_backward (basis in its reference layout, no extra memory: prepass + GEMM + reduce) and
-    fr_decode_3dmm_backward_packed (packed image, ONE fused kernel + reduce: the one the autograd node uses) are the same
+    """fr_decode_3dmm_backward (basis in its reference layout, no extra memory: prepass + GEMM + reduce),
+    fr_decode_3dmm_backward_packed (packed image, ONE fused kernel + reduce) and fr_decode_3dmm_backward_packed_mu (the same
+    kernel with d f formed from mu instead of the forward's output: the one the autograd node uses since round 5) are the same
     gradient with differently ordered -- each fixed -- partial sums: both within tolerance of the float64 gradient, each
     bit-reproducible, at a ragged shape (N = 187: the last vertex group is 11 vertices; 217 coefficients: 13 + 2 blocks, the
     last wave has one live), at the model's 199 + 29 with 70 faces (two passes) and at a one-block basis (staging-only waves)."""
@@ -149,9 +155,12 @@ def test_packed_and_reference_layout_entry_points(oracle, synth):
         ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         outs = []
-        for packed in (False, True, True, False):
+        for packed in (False, True, True, False, 2, 2):
             gp = torch.full_like(p, 7.0)
-            if packed:
+            if packed == 2:      # round 5: the same fused kernel with d f from mu -- no forward output in the call at all
+                rc = L.fr_decode_3dmm_backward_packed_mu(h.ptr(g), h.ptr(p), h.ptr(net.mu), h.ptr(net._basis.image_t()), None, B, N,
+                                                         ns, ne, 200.0, h.ptr(gp), h.ptr(ws), nws, st)
+            elif packed:
                 rc = L.fr_decode_3dmm_backward_packed(h.ptr(g), h.ptr(p), h.ptr(V), h.ptr(net._basis.image_t()), None, B, N, ns,
                                                       ne, 200.0, h.ptr(gp), h.ptr(ws), nws, st)
             else:
@@ -162,8 +171,12 @@ def test_packed_and_reference_layout_entry_points(oracle, synth):
             outs.append(gp.cpu().numpy().astype(np.float64))
         np.testing.assert_array_equal(outs[0], outs[3])      # each entry point reproduces its own bits
         np.testing.assert_array_equal(outs[1], outs[2])
+        np.testing.assert_array_equal(outs[4], outs[5])
+        keep = np.ones(outs[1].shape[1], bool)
+        keep[6] = False                                       # the mu form differs from the packed one in d f only -- bit for bit elsewhere
+        np.testing.assert_array_equal(outs[4][:, keep], outs[1][:, keep])
         want = oracle.decode_3dmm_backward_f64(G, P, A["mu"], A["pc_shape"], A["pc_exp"])
-        for got in (outs[0], outs[1]):
+        for got in (outs[0], outs[1], outs[4]):
             assert np.all(got[:, 0:3] == 0)
             for sl in (slice(3, 6), slice(6, 7), slice(7, 7 + ns), slice(7 + ns, None)):
                 if sl.start >= got.shape[1]:

@@ -331,3 +331,25 @@ def test_compute_abedo_image_and_mat_assets(tmp_path, small_assets):
                                          torch.zeros((2, 40, 40, 3), device="cuda:0"))
     assert torch.equal(alb, tex.clamp_min(1e-6).mean(-1, keepdim=True))
     assert float((tind >= 0).float().mean()) > 0.1
+
+
+def test_graphed_steps_replay_matches_the_serial_plan(full_assets, synth):
+    """pipeline.GraphedSteps: R batches per hipGraph -- every batch's planes and vertices bit-identical
+    to DecodeRenderPlan.step() on the same parameters, on the first replay and after new parameters."""
+    pipe = __import__("importlib").import_module("3dfacerecon_amd.pipeline")
+    B, R = 8, 3
+    net = net_mod().FaceRecNet(mesh_data=full_assets, batch_size=B, im_size=200)
+    serial = pipe.DecodeRenderPlan(net, B, 200, 200)
+    gs = pipe.GraphedSteps(net, B, R, 200, 200)
+    for rnd in range(2):
+        Ps = [torch.as_tensor(synth.sample_params_batch(B, beta=0.7, seed=70 + 10 * rnd + i), device="cuda:0") for i in range(R)]
+        outs = gs.replay(Ps)
+        torch.cuda.synchronize()
+        for i, P in enumerate(Ps):
+            want = [t.clone() for t in serial.step(P)]
+            torch.cuda.synchronize()
+            assert torch.equal(gs.plans[i].vertex_proj, serial.vertex_proj)
+            for g, w in zip(outs[i], want):
+                assert torch.equal(g, w)
+    with pytest.raises(ValueError):
+        pipe.GraphedSteps(net, B, 0)

@@ -35,4 +35,13 @@ for B in [int(x) for x in os.environ.get("BWD_B", "16,32,64").split(",")]:
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 30 * 1e3)
-    print("B=%d decode backward: %s us" % (B, " ".join("%.1f" % t for t in ts)), flush=True)
+    # host side of one backward through the autograd surface: wall clock per call with the GPU never waited for (the queue runs
+    # full: what the host spends issuing it), beside the device figure above
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        bwd()
+    host_us = (time.perf_counter() - t0) / 30 * 1e6
+    torch.cuda.synchronize()
+    print("B=%d decode backward: %s us   (host issue time per call %.1f us)" % (B, " ".join("%.1f" % t for t in ts), host_us), flush=True)
