@@ -119,8 +119,8 @@ enum Opt {
     OPT_BWD_CHUNKS,     // FR_BWD_CHUNKS     row chunks (workgroups, partial slabs) of the packed decode-backward GEMM: 256 (default: one workgroup per CU), 1 .. 512
     OPT_BWD_CB,         // FR_BWD_CB         16-coefficient blocks per wave of the fused decode backward: 0 = by batch (default) | 2 | 4
     OPT_EMIT_ORDER,     // FR_EMIT_ORDER     lane order of a segment's triangles: -1 scored per segment (default), 0 identity, 1 even / odd passes
-    OPT_Q30_SCHED,      // FR_Q30_SCHED      Q30 streaming schedule: 0 = 8 waves x whole tiles, 16-deep ring, staging launch (default) |
-                        //                   1 = the same with the parameter digits staged in-kernel | 2 = 16 waves, 32-column halves, 8-deep ring
+    OPT_Q30_SCHED,      // FR_Q30_SCHED      Q30 streaming schedule: 0 = 8 waves x whole tiles, 16-deep ring (default) | 1 = 16 waves, 32-column
+                        //                   halves on neighbouring waves, 8-deep ring
     OPT_COUNT
 };
 int opt(Opt o);

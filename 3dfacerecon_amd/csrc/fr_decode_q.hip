@@ -288,100 +288,6 @@ __device__ __forceinline__ void q_copy_stage(const char* __restrict__ stage, cha
 constexpr int QR_KB = 15, QR_S = 4, QR_NGL = 3, QR_F = 48;
 constexpr size_t QR_CB = (size_t)1024 * QR_KB, QR_TB = 3 * QR_CB + 256;
 
-// The same image built INSIDE the decode kernel, by every workgroup for itself, for the model's shape (S = 4 k-steps): the
-// staging launch costs the stream 5 us of kernel + a launch gap per pass, the in-kernel form ~2 us of each CU's time under
-// the latency of the ring's first requests.  Integer / fp32 forms of the specification's steps, each exact:
-//   * x 2^s is a power-of-two scaling of an fp32 number to at most 2^30: exact in fp32 (v_ldexp_f32; anything that would
-//     underflow rounds to 0 under rint either way), so rint(ldexp((double)x, s)) == (int)rndne(ldexp(x, s));
-//   * the four balanced base-256 digits of q are the bytes of (q + 0x808080) ^ 0x808080 (adding 128 to each of the three low
-//     bytes with carry is the digit recurrence; the xor turns the biased bytes into two's complement);
-//   * four consecutive k of one column are one dword per digit fragment: a 4 x 4 byte transpose in eight v_perm_b32.
-// Lane = (column & 15, k-quad & 3): a wave's ds_write_b32 then covers 64 consecutive dwords of a fragment (no bank conflicts),
-// and its parameter loads are sixteen 64-byte row pieces.  `scratch`: 3 KiB of LDS for the pose's sin / cos (float64).
-template <int DEC_BLOCK>
-__device__ __forceinline__ void q_stage_lds(const DecodeQArgs& a, char* lds, double* scratch, int tid, int nbatch) {
-    constexpr int NW = DEC_BLOCK / 64;
-    constexpr int ITEMS = 64 / NW;            // (column block, k-quad group) pairs per wave: 4 x 16 in all
-    static_assert(64 % NW == 0, "waves per workgroup");
-    char* Bimg = lds;
-    float* Mt = reinterpret_cast<float*>(Bimg + (size_t)QR_S * 16384);
-    int* be_s = reinterpret_cast<int*>(Mt + MAXB * 12);
-    const int lane = tid & 63, wave = tid >> 6;
-    const int b_lo = lane & 15, u_lo = lane >> 4;
-    const int K = a.qs.K;
-    const int nd = FR_N_POSE + a.d.ns + a.d.ne;
-    if (tid < MAXB) be_s[tid] = INT_MIN;
-    float x[ITEMS][4];
-    int cek[ITEMS][4];
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const int c = wave * ITEMS + it, nb = c >> 4, u = 4 * (c & 15) + u_lo, b = 16 * nb + b_lo;
-        const bool live = b < nbatch;
-        const float* pr = a.d.params + (size_t)(a.d.b0 + (live ? b : 0)) * nd + FR_N_POSE;
-        const int4 c4 = *reinterpret_cast<const int4*>(a.ce + 4 * u);
-        cek[it][0] = c4.x; cek[it][1] = c4.y; cek[it][2] = c4.z; cek[it][3] = c4.w;
-        // unconditional, clamped loads, all issued before any is consumed (a load under its own `k < K` predicate becomes a
-        // branch with a vmcnt(0) of its own: thirty-two dependent round trips per thread, measured +6 us per launch)
-#pragma unroll
-        for (int t = 0; t < 4; t++) x[it][t] = pr[min(4 * u + t, K > 0 ? K - 1 : 0)];
-    }
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++)
-#pragma unroll
-        for (int t = 0; t < 4; t++) asm volatile("" : "+v"(x[it][t]));
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const int c = wave * ITEMS + it, u = 4 * (c & 15) + u_lo, b = 16 * (c >> 4) + b_lo;
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-            if (!(b < nbatch && 4 * u + t < K)) x[it][t] = 0.f;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // be_s initialised
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const int c = wave * ITEMS + it, b = 16 * (c >> 4) + b_lo;
-        int e = INT_MIN;
-        bool bad = false;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const float v = x[it][t];
-            if (!isfinite(v)) bad = true;
-            else if (v != 0.f) e = max(e, __builtin_amdgcn_frexp_expf(v) + cek[it][t]);
-        }
-        if (bad) atomicMax(&be_s[b], Q_BE_BAD);
-        else if (e != INT_MIN) atomicMax(&be_s[b], e);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const int c = wave * ITEMS + it, nb = c >> 4, uh = c & 15, b = 16 * nb + b_lo;
-        int be = be_s[b];
-        if (be == INT_MIN) be = 0;
-        unsigned W[4] = {0u, 0u, 0u, 0u};
-        if (be != Q_BE_BAD) {
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int q = (int)__builtin_rintf(__builtin_ldexpf(x[it][t], cek[it][t] + 30 - be));
-                W[t] = ((unsigned)q + 0x808080u) ^ 0x808080u;
-            }
-        }
-        const unsigned h01 = __builtin_amdgcn_perm(W[1], W[0], 0x06020703u), l01 = __builtin_amdgcn_perm(W[1], W[0], 0x04000501u);
-        const unsigned h23 = __builtin_amdgcn_perm(W[3], W[2], 0x06020703u), l23 = __builtin_amdgcn_perm(W[3], W[2], 0x04000501u);
-        unsigned o[4];
-        o[0] = __builtin_amdgcn_perm(h23, h01, 0x05040100u);
-        o[1] = __builtin_amdgcn_perm(h23, h01, 0x07060302u);
-        o[2] = __builtin_amdgcn_perm(l23, l01, 0x05040100u);
-        o[3] = __builtin_amdgcn_perm(l23, l01, 0x07060302u);
-        const int sidx = uh >> 2, g = uh & 3;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            *reinterpret_cast<unsigned*>(Bimg + ((size_t)((sidx * 4 + j) * 4 + nb) * 64 + g * 16 + b_lo) * 16 + 4 * u_lo) = o[j];
-    }
-    if (tid < MAXB && tid >= nbatch) be_s[tid] = 0;
-    else if (tid < MAXB && be_s[tid] == INT_MIN) be_s[tid] = 0;
-    pose_prologue<MAXB>(a.d, Mt, scratch, tid, nd, nbatch);   // two barriers: publishes the image, be_s and Mt
-}
-
 // One coordinate's LV level sums -> fl32(mu + h 2^(be - e_r - 60 + 8 (7 - LV))) for this lane's 4 rows x NBW columns, h the
 // written chain h = fl64(h * 256 + L_s).  Two steps are taken in cheaper, bit-identical forms: the leading digits of the
 // 31-bit operands are at most 64 in magnitude, so with K <= 512 coefficients |L_0| <= 2^21 and |L_1| <= 2^23 and
@@ -509,8 +415,7 @@ __host__ __device__ constexpr size_t qr_off(int f) {
 // H2: waves that share a tile (1: a wave owns all of a tile's NBW column blocks; 2: NBW = 2 and the tile's two 32-column halves
 // go to neighbouring waves, which stream the same fragments at the same time -- the second request is an L1 / L2 hit -- so that
 // the accumulators of one wave (LV x NBW x 4 registers) leave room for four waves per SIMD).
-// STAGE: the parameter image is built in-kernel (q_stage_lds) instead of copied from the staging launch's buffer.
-template <int R, int NBW, int DEC_WAVES, int WPE, bool NT, int LV, int H2, bool STAGE>
+template <int R, int NBW, int DEC_WAVES, int WPE, bool NT, int LV, int H2>
 __global__ __launch_bounds__(DEC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void decode_q_ring_kernel(DecodeQArgs a) {
     constexpr int DEC_BLOCK = DEC_WAVES * 64;
@@ -541,16 +446,12 @@ void decode_q_ring_kernel(DecodeQArgs a) {
         const char* sb_ = Tb + (size_t)(t_) * QR_TB + qr_off(f_);                \
         FRQ_LD(ring[slot_], sb_, voffA);                                         \
     }
-    // (STAGE: the parameter loads must not queue behind the ring's first requests -- vmcnt returns in order, and the priming
-    // burst of every CU at once is 32 MB of cold HBM reads -- so the image is built first and the ring primed after it;
-    // primed first, with the staging behind it, the kernel measured the same)
-    if constexpr (STAGE) q_stage_lds<DEC_BLOCK>(a, qsmem, reinterpret_cast<double*>(park_s), tid, nbatch);
     {
         const int t0c = tile0 < tiles ? tile0 : 0;
 #pragma unroll
         for (int f = 0; f < R; f++) FRQ_REQ(f, f, t0c)
     }
-    if constexpr (!STAGE) q_copy_stage<DEC_BLOCK>(a.stage, qsmem, QR_S, tid);
+    q_copy_stage<DEC_BLOCK>(a.stage, qsmem, QR_S, tid);
     if (tile0 >= tiles) {
 #pragma unroll
         for (int f = 0; f < R; f++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[f]));
@@ -684,36 +585,33 @@ static int launch_q_generic(const fr::DecodeQArgs& a, size_t lds, int cus, hipSt
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
-template <int R, int NBW, int WAVES, int WPE, int LV, int H2, bool STAGE = false>
+template <int R, int NBW, int WAVES, int WPE, int LV, int H2>
 static int launch_q_ring(const fr::DecodeQArgs& a, int cus, hipStream_t stream) {
     static fr_lds_flags_t lds_ok[64];
-    const void* k = reinterpret_cast<const void*>(&fr::decode_q_ring_kernel<R, NBW, WAVES, WPE, true, LV, H2, STAGE>);
+    const void* k = reinterpret_cast<const void*>(&fr::decode_q_ring_kernel<R, NBW, WAVES, WPE, true, LV, H2>);
     if (fr_allow_full_lds(k, lds_ok) != hipSuccess) return FR_ERR_LAUNCH;
     const size_t lds = fr::q_stage_bytes(fr::QR_S) + (size_t)WAVES * 256 + (size_t)WAVES * 2 * NBW * 1024;
     const int tiles = fr::tiles_of(a.d.N);
     const int slots = WAVES / H2;
     const int grid = (int)min((long long)cus, (long long)(tiles + slots - 1) / slots);
-    static_assert(!STAGE || (size_t)WAVES * 2 * NBW * 1024 >= 3072, "the pose scratch lives in the parking area");
-    hipLaunchKernelGGL((fr::decode_q_ring_kernel<R, NBW, WAVES, WPE, true, LV, H2, STAGE>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((fr::decode_q_ring_kernel<R, NBW, WAVES, WPE, true, LV, H2>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 
 // One pass (<= 64 columns, nbt live 16-column blocks) of the model's basis shape through the streaming schedule.
 //   sched 0 (default): 8 waves per CU, a wave owns a tile's nbt column blocks (every basis byte is requested once on the chip),
 //                      16-deep fragment ring, behind the staging launch (q_stage_kernel)
-//   sched 1: the same kernel with the parameter image built in-kernel (q_stage_lds: no staging launch).  Measured equal one
-//            batch at a time and 2.5 us slower with two batches in flight, where the staging launch hides behind the other
-//            stream's kernels (profiles/round5_probes/r5b)
-//   sched 2: 16 waves per CU at <= 128 registers (12 at <= 168 with all seven levels), 8-deep ring, a full pass cut into two
+//   sched 1: 16 waves per CU at <= 128 registers (12 at <= 168 with all seven levels), 8-deep ring, a full pass cut into two
 //            32-column halves per tile taken by neighbouring waves (the f32 kernel's arrangement; measured 2-7 us slower: the
 //            partner's request of a non-temporal fragment misses L2 too often)
+// Measured and not kept (profiles/round5_probes/r5b): the staging WITHOUT its launch -- every workgroup building the whole
+// parameter image for itself (integer / fp32 forms of the same steps): equal one batch at a time, 2.5 us slower with two batches
+// in flight; the kernel's first 64 workgroups staging one column each and all 256 waiting for them on an agent-scope counter
+// (release / acquire hand-off): +6 us -- the hand-off costs more than the launch gap it removes; a decode that leaves half of
+// every CU to the other stream's emit workgroups: +9 us in flight.
 template <int LV>
 static int launch_q_pass(const fr::DecodeQArgs& a, int nbt, int sched, int cus, hipStream_t stream) {
-    if (sched == 1)
-        return nbt == 1 ? launch_q_ring<16, 1, 8, 2, LV, 1, true>(a, cus, stream)
-               : nbt == 2 ? launch_q_ring<16, 2, 8, 2, LV, 1, true>(a, cus, stream)
-                          : launch_q_ring<16, 4, 8, 2, LV, 1, true>(a, cus, stream);
-    if (sched != 2 || nbt <= 2)
+    if (sched != 1 || nbt <= 2)
         return nbt == 1 ? launch_q_ring<16, 1, 8, 2, LV, 1>(a, cus, stream)
                : nbt == 2 ? launch_q_ring<16, 2, 8, 2, LV, 1>(a, cus, stream)
                           : launch_q_ring<16, 4, 8, 2, LV, 1>(a, cus, stream);
@@ -767,7 +665,7 @@ int fr_launch_decode_q(const float* params, const void* qimage, const float* R_o
         a.d.b0 = b0;
         const int nbt = (min(B - b0, MAXB) + 15) / 16;
         const bool ring = !loop_env && a.qs.KB == QR_KB;
-        if (!(ring && sched == 1)) hipLaunchKernelGGL(q_stage_kernel, dim3(MAXB), dim3(128), 0, stream, a, stage);
+        hipLaunchKernelGGL(q_stage_kernel, dim3(MAXB), dim3(128), 0, stream, a, stage);
         int rc;
         if (ring)   // the model's basis shape: streaming schedule
             rc = levels == 7 ? launch_q_pass<7>(a, nbt, sched, cus, stream)

@@ -218,9 +218,9 @@ int fr_decode_render_pipelined(const float* params, const void* packed_basis, co
  * for which fr_decode_q30_pack / fr_decode_3dmm_q30 return FR_ERR_UNSUPPORTED; the image does not depend on `levels`) and
  * needs a caller-owned staging workspace (fr_decode_q30_workspace_bytes: 68 KiB for the model's shape, 16-byte aligned) that
  * must not be shared by launches in flight on different streams.  fr_decode_3dmm_q30 is levels = 7 on dense [B,3,N] rows.
- * FR_Q30_SCHED (fr_set_option): 0 = 8 waves per CU, whole tiles, 16-deep ring, behind a staging launch (default) | 1 = the same
- * with the parameter digits staged inside the kernel | 2 = 16 waves per CU, a tile's two 32-column halves on neighbouring
- * waves; no result bit depends on it (profiles/round5_probes/r5b: what each measured). */
+ * FR_Q30_SCHED (fr_set_option): 0 = 8 waves per CU, a wave owns a tile's four column blocks, 16-deep ring (default) | 1 = 16
+ * waves per CU, a tile's two 32-column halves on neighbouring waves; no result bit depends on it (profiles/round5_probes/r5b:
+ * what each measured, and the launch-free staging forms that were built and not kept). */
 size_t fr_decode_q30_image_bytes(int N, int n_shape, int n_exp);
 int fr_decode_q30_pack(const float* mu, const float* pc_shape, const float* pc_exp, int N, int n_shape, int n_exp,
                        void* qimage, size_t qimage_bytes, void* hip_stream);

@@ -77,7 +77,7 @@ def test_vs_q30_spec_bit_exact(q30_mode, oracle, synth, gu, gv, ns, ne, B):
     want = oracle.decode_3dmm_q30(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R, levels=q30_mode.levels)
     got = _decode_gpu(net, P, R)
     np.testing.assert_array_equal(got, want)
-    for sched in (1, 2):   # the in-kernel staging and the two-halves schedule: the same bits
+    for sched in (1,):   # the two-halves schedule: the same bits
         with q30_mode.options(FR_Q30_SCHED=sched):
             np.testing.assert_array_equal(_decode_gpu(net, P, R), want, err_msg="FR_Q30_SCHED=%d" % sched)
     # against the reference's arithmetic type (f32 chain spec): both are within a few ulp of the float64 evaluation
@@ -111,7 +111,7 @@ def test_special_values(q30_mode, oracle, synth):
     want = oracle.decode_3dmm_q30(P, A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R, levels=q30_mode.levels)
     np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
     np.testing.assert_array_equal(got[~np.isnan(want)], want[~np.isnan(want)])
-    with q30_mode.options(FR_Q30_SCHED=1):   # the in-kernel staging's integer / fp32 forms of the same steps
+    with q30_mode.options(FR_Q30_SCHED=1):
         np.testing.assert_array_equal(_decode_gpu(net, P, R), got)
     assert np.isnan(got[1]).all() and np.isnan(got[2]).all() and not np.isnan(got[[0, 3, 4, 5, 6, 7, 8]]).any()
 
@@ -152,7 +152,7 @@ def test_full_size_batch64(q30_mode, oracle, full_assets, synth):
     for b in (0, 63):
         want = oracle.decode_3dmm_q30(P[b:b + 1], A["mu"], A["pc_shape"], A["pc_exp"], 200.0, R=R[b:b + 1], levels=q30_mode.levels)
         np.testing.assert_array_equal(got[b:b + 1], want)
-    for sched in (1, 2):
+    for sched in (1,):
         with q30_mode.options(FR_Q30_SCHED=sched):
             np.testing.assert_array_equal(_decode_gpu(net, P, R), got, err_msg="FR_Q30_SCHED=%d" % sched)
     # deterministic; a face's result does not depend on what else is in the batch (its scale is its own)

@@ -123,7 +123,7 @@ def test_decode_both_arithmetics(oracle, synth, seed):
     h = pkg("_lib")
     prev, prev_lv = h.decode_arith(), h.q30_levels()
     lv = int(rs.choice([7, 5, 4]))          # digit-product levels of the Q30 leg
-    sched = int(rs.choice([0, 1, 2]))       # and its schedule (matters for the model's shape only)
+    sched = int(rs.choice([0, 1]))       # and its schedule (matters for the model's shape only)
     try:
         for mode, q30 in ((1, False), (0, lv)):
             h.set_decode_arith(mode, lv)
