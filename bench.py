@@ -792,6 +792,15 @@ def main():
                 "why_not_value": "the two arithmetics are two written definitions of the same blend, each held to its own CPU "
                                  "restatement bit for bit; `value` stays on the f32 chain (the reference's arithmetic type, the "
                                  "figure rounds 1-4 reported).  Same route, same K / W / R, same slots' parameters"}
+        # north_star: ">= 40 % of the HBM roofline" = algorithmic bytes per face x faces/s >= 0.4 x 8 TB/s, per GPU
+        need = 0.4 * HBM_PEAK_GBS * 1e9 / ab["pipeline"]
+        out["north_star_40pct_of_8TBs"] = {
+            "needs_faces_per_s_per_gpu": need, "needs_ms_per_step": 1e3 * B / need,
+            "value (f32 chain, %s)" % out["value_route"]: bool(value / world >= need),
+            "value_one_batch_at_a_time (f32 chain, serial plan)": (bool(faces_per_step * K / serial_elapsed / world >= need)
+                                                                   if serial_elapsed is not None else None),
+            "q30_inflight (Q30 decode, %s)" % out["value_route"]: (bool(out["q30_inflight_faces_per_s"] / world >= need)
+                                                                    if q30_leg is not None else None)}
         if allreduce is not None:
             out["dist"]["allreduce_preflight"] = allreduce
         if args.scaling == "strong":   # what one GPU's shard was measured to take (profiles/round3_strong_scaling_shards.json)

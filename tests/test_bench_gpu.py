@@ -51,6 +51,18 @@ def test_bench_line_one_gpu():
     assert d["dist"]["distinct_devices"] and d["dist"]["devices"][0]["name"] and d["dist"]["devices"][0]["id"]
     assert all("avg_ms_is" in d["kernels"][k] for k in ("decode", "raster_emit", "resolve_write"))
     assert "which_side_binds" in d["kernels"]["decode"]
+    # round 5: what the headline means, one batch's latency, the clock the part held, the one-batch-at-a-time figure, and the
+    # same route with the Q30 decode (ten digit products), gated against ITS oracle, beside `value`
+    assert d["value_route"] == "inflight" and "THROUGHPUT" in d["value_meaning"]
+    assert d["per_batch_latency_ms"] > d["ms_per_step"]          # two in flight: a batch takes longer than the interval
+    assert abs(d["config"]["value_one_batch_at_a_time"] - d["serial_plan_faces_per_s"]) < 1e-6 * d["value"]
+    for k in ("after_timed_blocks", "after_serial_leg"):
+        assert 1.0 < d["clock_GHz_held"][k]["median"] < 2.6
+    assert d["vector_pipe"] is None or d["vector_pipe"]["clock_GHz_held"] == d["clock_GHz_held"]["after_timed_blocks"]["median"]
+    q = d["q30_inflight"]
+    assert q["parity"]["ok"] and q["parity"]["mismatching_planes"] == 0 and q["parity"]["faces_checked"] == 16
+    assert d["q30_inflight_faces_per_s"] > 1e4 and abs(q["vs_value"] - d["q30_inflight_faces_per_s"] / d["value"]) < 1e-9
+    assert "4 digit-product levels" in q["decode_arith"] and d["config"]["decode_arith"].startswith("f32")
 
 
 def test_bench_line_serial_route():
@@ -88,3 +100,6 @@ def test_bench_two_ranks_walk_the_multi_rank_flow(scaling, global_faces, local_f
     ar = d["dist"]["allreduce_preflight"]
     assert ar["sum_correct"] and ar["bytes"] == 4000000 and ar["ms"] > 0
     assert ("strong_scaling_prediction" in d["dist"]) == (scaling == "strong")
+    if scaling == "strong":   # (read from the committed shard timings, not literals)
+        sp = d["dist"]["strong_scaling_prediction"]
+        assert sp["predicted_speedup_vs_1_gpu"]["8"] > 1.5 and sp["us_per_step_at_faces_per_gpu"]["64"] > 50

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Round-5 development probe: the three forms of the fused decode backward's d f in ONE process, interleaved rounds, raw C ABI
-(no autograd): 'vproj' = fr_decode_3dmm_backward_packed (round 4: reads the forward's output), 'mu_lds' / 'mu_gather' =
-fr_decode_3dmm_backward_packed_mu with the parameters staged in LDS / gathered at the kernel's end (FR_BWD_XS = 1 / 0)."""
+"""Round-5 development probe: the two forms of the fused decode backward's d f in ONE process, interleaved rounds, raw C ABI
+(no autograd): 'vproj' = fr_decode_3dmm_backward_packed (reads the forward's output), 'mu' = fr_decode_3dmm_backward_packed_mu
+(d f from mu and the coefficient gradients: no forward output).  (profiles/round5_probes/r5d also holds the LDS-staged
+variant of the mu form, which was measured with this script and removed.)"""
 import ctypes
 import importlib
 import json
@@ -34,10 +35,9 @@ for B in (64, 32, 16):
         if kind == "vproj":
             return L.fr_decode_3dmm_backward_packed(h.ptr(G), h.ptr(P), h.ptr(V), h.ptr(img), None, B, net.nvert, 199, 29, 200.0,
                                                     h.ptr(gp), h.ptr(ws), nws, st)
-        h.set_option("FR_BWD_XS", 1 if kind == "mu_lds" else 0)
         return L.fr_decode_3dmm_backward_packed_mu(h.ptr(G), h.ptr(P), h.ptr(net.mu), h.ptr(img), None, B, net.nvert, 199, 29, 200.0,
                                                    h.ptr(gp), h.ptr(ws), nws, st)
-    res = {k: [] for k in ("vproj", "mu_lds", "mu_gather")}
+    res = {k: [] for k in ("vproj", "mu")}
     for k in res:
         for _ in range(5):
             assert run(k) == 0
@@ -53,5 +53,4 @@ for B in (64, 32, 16):
             res[k].append(round(e0.elapsed_time(e1) / 50 * 1e3, 2))
     out["B=%d" % B] = res
     print("B=%d" % B, res, flush=True)
-h.set_option("FR_BWD_XS", 1)
 print(json.dumps({"what": "us per backward (fused kernel + reduce, both launches), 50 calls per figure, four interleaved rounds, one process", "results": out}))

@@ -34,7 +34,8 @@ def kernel_stats(name, out):
                                  for r in hot}}
 
 
-for j in ("bench", "bench_k20", "bench_serial", "bench_pipelined", "bench_graph", "bench_q30"):
+for j in ("bench", "bench_again", "bench_k20", "bench_serial", "bench_pipelined", "bench_graph", "bench_q30", "bench_q30l5", "bench_q30l4",
+          "phase_test", "inflight_timeline", "pmc_summary_q30l4"):
     f = os.path.join(src, j + ".json")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.json" % (tag, j)))
@@ -42,6 +43,11 @@ kernel_stats("prof_bench", "%s_kernel_stats.csv" % tag)
 kernel_stats("prof_bwd", "%s_decode_bwd_kernel_stats.csv" % tag)
 kernel_stats("prof_pipelined", "%s_pipelined_kernel_stats.csv" % tag)
 kernel_stats("prof_inflight", "%s_inflight_kernel_stats.csv" % tag)
+kernel_stats("prof_q30l4", "%s_q30l4_kernel_stats.csv" % tag)
+for lg in ("bwd_probe.log", "bwd_ab.log", "legs.log", "kernel_timing.log"):
+    f = os.path.join(src, lg)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(P, "%s_%s" % (tag, lg)))
 # the bench line printed by the SAME process the kernel stats come from (profiled: lower clocks, per-launch overhead)
 f = os.path.join(src, "prof_bench.log")
 if os.path.exists(f):
@@ -122,7 +128,8 @@ for extra in ("kernel_timing.log", "decode_breakdown.json", "emit_phase_account.
     f = os.path.join(src, extra)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s" % (tag, extra)))
-f = os.path.join(ROOT, "gpurun_out", "parity_depth_vs_f64.json")
-if os.path.exists(f):
-    shutil.copy(f, os.path.join(P, "%s_parity_depth_vs_f64.json" % tag))
+for sfx in ("", "_q30", "_q30l5", "_q30l4"):
+    f = os.path.join(ROOT, "gpurun_out", "parity_depth_vs_f64%s.json" % sfx)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(P, "%s_parity_depth_vs_f64%s.json" % (tag, sfx)))
 print(sorted(os.listdir(P)))
