@@ -205,11 +205,29 @@ __global__ __launch_bounds__(128) void q_stage_kernel(DecodeQArgs a, char* __res
     const bool mine = 4 * tid < 64 * S;
     int e = INT_MIN;
     bool bad = false;
+    // the eight loads of a thread are unconditional (clamped) and issued together: written as `cond ? load : 0` each becomes a
+    // branch with its own s_waitcnt vmcnt(0) -- eight dependent round trips, most of what this kernel used to take
+    float pose[FR_N_POSE];   // (the column's seven pose parameters: the same round trip, not one more behind each branch below)
+    {
+        const int kmax = K > 0 ? K - 1 : 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int kc = min(4 * tid + t, kmax);
+            x[t] = pr[FR_N_POSE + kc];
+            cek[t] = a.ce[kc];
+        }
+#pragma unroll
+        for (int i = 0; i < FR_N_POSE; i++) pose[i] = pr[i];
+#pragma unroll
+        for (int t = 0; t < 4; t++) asm volatile("" : "+v"(x[t]), "+v"(cek[t]));
+#pragma unroll
+        for (int i = 0; i < FR_N_POSE; i++) asm volatile("" : "+v"(pose[i]));
+    }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int k = 4 * tid + t;
-        x[t] = (live && k < K) ? pr[FR_N_POSE + k] : 0.f;
-        cek[t] = (mine && k < K) ? a.ce[k] : 0;
+        if (!(live && k < K)) x[t] = 0.f;
+        if (!(mine && k < K)) cek[t] = 0;
         if (!isfinite(x[t])) bad = true;
         else if (x[t] != 0.f) e = max(e, __builtin_amdgcn_frexp_expf(x[t]) + cek[t]);
     }
@@ -217,7 +235,7 @@ __global__ __launch_bounds__(128) void q_stage_kernel(DecodeQArgs a, char* __res
     else if (e != INT_MIN) atomicMax(&be_sh, e);
     if (tid < 3 && live && !a.d.R_override) {
         double sn, cs;
-        sincos((double)pr[tid], &sn, &cs);
+        sincos((double)(tid == 0 ? pose[0] : tid == 1 ? pose[1] : pose[2]), &sn, &cs);
         sc_sh[2 * tid] = sn;
         sc_sh[2 * tid + 1] = cs;
     }
@@ -263,12 +281,12 @@ __global__ __launch_bounds__(128) void q_stage_kernel(DecodeQArgs a, char* __res
             } else {
                 rotation_from_sincos(sc_sh[0], sc_sh[1], sc_sh[2], sc_sh[3], sc_sh[4], sc_sh[5], R);
             }
-            const float f = pr[6];
+            const float f = pose[6];
 #pragma unroll
             for (int i = 0; i < 9; i++) m[i] = f * R[i];  // f (.) R elementwise, network.py:163-165
-            m[9] = pr[3];
-            m[10] = pr[4];
-            m[11] = pr[5];
+            m[9] = pose[3];
+            m[10] = pose[4];
+            m[11] = pose[5];
         }
 #pragma unroll
         for (int i = 0; i < 12; i++) Mt[i] = m[i];
@@ -608,7 +626,9 @@ static int launch_q_ring(const fr::DecodeQArgs& a, int cus, hipStream_t stream) 
 // parameter image for itself (integer / fp32 forms of the same steps): equal one batch at a time, 2.5 us slower with two batches
 // in flight; the kernel's first 64 workgroups staging one column each and all 256 waiting for them on an agent-scope counter
 // (release / acquire hand-off): +6 us -- the hand-off costs more than the launch gap it removes; a decode that leaves half of
-// every CU to the other stream's emit workgroups: +9 us in flight.
+// every CU to the other stream's emit workgroups: +9 us in flight; write-through (sc0 sc1) stores of the vertex rows: 0, non-
+// temporal ones: +4 us (the emit kernel's event bracket is ~2 us longer behind this kernel than behind the f32 one under every
+// store policy, while rocprofv3 shows the same 40.5 us emit kernel: the difference sits in the kernel boundary).
 template <int LV>
 static int launch_q_pass(const fr::DecodeQArgs& a, int nbt, int sched, int cus, hipStream_t stream) {
     if (sched != 1 || nbt <= 2)
