@@ -14,11 +14,12 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_from_env(backend=None):
-    """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1.
+def init_from_env(backend=None, force=False):
+    """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1 (force=True: also for a
+    single rank -- a one-rank RCCL group is how the one-GPU box can exercise the collective library at all).
     Returns (world, rank, local_rank)."""
     world, rank, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -165,6 +166,34 @@ def allreduce_preflight(megabytes, device="cpu", iters=5):
     return {"bytes": nbytes, "ms": 1e3 * sec, "algbw_GBs": nbytes / sec / 1e9,
             "busbw_GBs": nbytes / sec / 1e9 * 2.0 * (n - 1) / n, "sum_correct": ok, "iters": iters,
             "what": "one SUM all-reduce of config 4's gradient size on the bench's own process group"}
+
+
+def rccl_selftest(device, megabytes=302.0):
+    """ONE-rank RCCL group on `device` (only when no group exists yet): librccl is loaded, a communicator is created on this GPU
+    and a SUM all-reduce of config 4's gradient size runs through it; then the group is destroyed.  What a one-GPU box can
+    show of the collective library: that it initialises and that the call path torch DDP uses works here -- NOT bandwidth
+    (one rank moves nothing over xGMI).  Returns a record; never raises (a failure is reported in the record)."""
+    import socket
+    if dist.is_available() and dist.is_initialized():
+        return {"skipped": "a process group already exists"}
+    rec = {"backend": "nccl", "world_size": 1, "rccl_version": collective_library()}
+    try:
+        with socket.socket() as sck:
+            sck.bind(("127.0.0.1", 0))
+            port = sck.getsockname()[1]
+        dev = torch.device(device)
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port, device_id=dev)
+        try:
+            rec["allreduce"] = allreduce_preflight(megabytes, device=dev, iters=3)
+            rec["describe"] = {k: v for k, v in describe(dev).items() if k != "devices"}
+            rec["ok"] = bool(rec["allreduce"] and rec["allreduce"]["sum_correct"] and rec["describe"]["backend"] == "nccl")
+        finally:
+            dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001 -- the self-test must not take the bench line down
+        rec["ok"] = False
+        rec["error"] = "%s: %s" % (type(e).__name__, e)
+    return rec
 
 
 def bench_partition(batch, rank, world, scaling="weak"):

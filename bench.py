@@ -294,6 +294,9 @@ def main():
     ap.add_argument("--allreduce-mb", type=float, default=-1.0,
                     help="N > 1: time one SUM all-reduce of this many MB on the bench's process group before the timed "
                          "region (config 4's gradient is ~302 MB) and report bus GB/s.  -1 = 302 under nccl, 4 under gloo; 0 = skip")
+    ap.add_argument("--no-rccl-selftest", action="store_true",
+                    help="N = 1: skip the one-rank RCCL self-test (utils.dist.rccl_selftest: communicator on this GPU + one "
+                         "302 MB all-reduce through it, reported as dist.rccl_selftest)")
     ap.add_argument("--config", type=int, default=0, choices=(0, 3, 4, 5),
                     help="3 / 4 / 5: run the caller config of BASELINE.json (examples/coarse_loop.py --config N --steps K) "
                          "instead of the headline hot-path bench, and print ITS line")
@@ -601,6 +604,9 @@ def main():
                                                       "planes_identical_to_the_serial_plan": bool(same)}
             del gs
 
+    rccl_st = None
+    if world == 1 and not args.no_rccl_selftest:   # (after everything timed: the one-GPU box's only contact with RCCL)
+        rccl_st = dist_u.rccl_selftest(dev)
     if rank == 0:
         N, T, Kc = net.nvert, int(net.tri.shape[1]), net.ndim_shape + net.ndim_exp
         ab = algorithmic_bytes(N, T, Kc, H, W, B)
@@ -801,6 +807,8 @@ def main():
                                                                    if serial_elapsed is not None else None),
             "q30_inflight (Q30 decode, %s)" % out["value_route"]: (bool(out["q30_inflight_faces_per_s"] / world >= need)
                                                                     if q30_leg is not None else None)}
+        if rccl_st is not None:
+            out["dist"]["rccl_selftest"] = rccl_st
         if allreduce is not None:
             out["dist"]["allreduce_preflight"] = allreduce
         if args.scaling == "strong":   # what one GPU's shard was measured to take (profiles/round3_strong_scaling_shards.json)

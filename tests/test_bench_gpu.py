@@ -63,6 +63,10 @@ def test_bench_line_one_gpu():
     assert q["parity"]["ok"] and q["parity"]["mismatching_planes"] == 0 and q["parity"]["faces_checked"] == 16
     assert d["q30_inflight_faces_per_s"] > 1e4 and abs(q["vs_value"] - d["q30_inflight_faces_per_s"] / d["value"]) < 1e-9
     assert "4 digit-product levels" in q["decode_arith"] and d["config"]["decode_arith"].startswith("f32")
+    # ... and the one-GPU box's contact with RCCL: a one-rank communicator on this GPU and one all-reduce through it
+    st = d["dist"]["rccl_selftest"]
+    assert st["ok"], st
+    assert st["describe"]["backend"] == "nccl" and st["rccl_version"] and st["allreduce"]["sum_correct"] and st["allreduce"]["bytes"] == 302000000
 
 
 def test_bench_line_serial_route():
