@@ -314,6 +314,13 @@ def main():
     if args.gpus > 1 and world_env == 1 and "RANK" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
 
+    # ONE line on stdout, whatever the libraries print: RCCL writes a version banner to file descriptor 1 when its first
+    # communicator comes up (MIOpen and the runtime have their own moods).  From here on fd 1 is stderr; the JSON line goes to
+    # the saved real stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     dist_u = pkg("utils.dist")
@@ -840,7 +847,8 @@ def main():
                     value / cb["north_star_reference_cpu_zbuffer"]["faces_per_s"]}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     dist_u.barrier()
     dist_u.finalize()
 

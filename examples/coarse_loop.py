@@ -37,6 +37,9 @@ def pkg(n):
     return importlib.import_module("3dfacerecon_amd." + n)
 
 
+_emit = lambda rec: print(json.dumps(rec))   # noqa: E731  (main() points it at the real stdout)
+
+
 def build_harness(args, dev, rank, world, local):
     """model (DDP-wrapped when training on > 1 rank), optimiser, step() closure."""
     synth, netm, cn, losses = pkg("utils.synth"), pkg("nets.network"), pkg("nets.coarse_net"), pkg("nets.losses")
@@ -140,7 +143,7 @@ def run_test_phase(args, dev, rank, world, local, dist_u):
     same = all(torch.equal(a, b) for a, b in zip(sums, ref))
     dist_info = dist_u.describe(device=dev)
     if rank == 0:
-        print(json.dumps({"metric": "faces/sec, evaluation loop (trainval.py:192-210): CoarseNet x %d + depth rendering" % args.nIter,
+        _emit(dict({"metric": "faces/sec, evaluation loop (trainval.py:192-210): CoarseNet x %d + depth rendering" % args.nIter,
                           "value": world * B * args.steps / dt, "unit": "faces/s", "higher_is_better": True, "data": "synthetic",
                           "dtype": "f32", "phase": "test", "n_gpus": world, "faces_per_gpu": B, "im_size": S, "steps": args.steps,
                           "ms_per_step": 1e3 * dt / args.steps, "batches_in_flight": len(flights.slots),
@@ -191,6 +194,13 @@ def main():
                     help="trainval.py's phase switch (:223-225).  test = the forward-only evaluation loop over independent batches "
                          "with the depth rendering in flight (run_test_phase); train = everything else this script does")
     args = ap.parse_args()
+    # (ONE line on stdout: RCCL prints a version banner to fd 1 when its first communicator comes up -- from here on fd 1 is
+    # stderr and the JSON line goes to the saved real stdout)
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    global _emit
+    _emit = lambda rec: os.write(real_stdout, (json.dumps(rec) + "\n").encode())   # noqa: E731
     dist_u = pkg("utils.dist")
     world, rank, local = dist_u.init_from_env()
     if args.phase == "test":
@@ -233,7 +243,7 @@ def main():
                "params_finite": bool(torch.isfinite(out["pred_params"]).all())}
         if L is not None:
             rec["losses"] = {k: float(v) for k, v in L.items()}
-        print(json.dumps(rec))
+        _emit(rec)
     dist_u.finalize()
 
 

@@ -28,6 +28,8 @@ def _line(cmd):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]          # ONE line, from rank 0
+    # ... and nothing else on stdout: RCCL's version banner, MIOpen's chatter etc. go to stderr (bench.py points fd 1 there)
+    assert [l for l in p.stdout.splitlines() if l.strip()] == lines, p.stdout[:2000]
     return json.loads(lines[0])
 
 
