@@ -9,7 +9,10 @@
 //   qA[r,k] = rint(A[r,k] 2^(30 - re_r - ce_k))   (per-row and per-column power-of-two scales; |qA| <= 2^30)
 //   qB[k,b] = rint(x[b,k] 2^(30 - be_b + ce_k))
 //   v[r,b]  = fl32( mu_r + (sum_k qA qB) 2^(re_r + be_b - 60) )
-// with qA, qB split into four balanced base-256 digits each and all 16 digit products accumulated in int32 by the MFMA.
+// with qA, qB split into four balanced base-256 digits each and the digit products a_i b_j (weight 256^(6-i-j)) accumulated in
+// int32 level sums by the MFMA.  LV (template argument of the kernels, `levels` of the entry points) = how many of the seven
+// levels i + j = 0 .. 6 are kept: 7 = all sixteen products (the exact product), 5 = thirteen, 4 = ten -- what is dropped lies
+// below 2^-38 / 2^-30 of a term's full scale; round 5: the ten-product kernel is 13 us shorter than the f32 kernel (rocprofv3).
 // Entries within 2^-6 of their row's maximum are represented exactly; the quantisation error of the rest is below
 // 2^-31 of the row / column maximum, so the result is the correctly rounded fp32 value of the real-number blend in
 // 99.7 % of the cases on the model's data (mean error 0.25 ulp against the f32 chain's 0.5; tests/test_decode_q30_*.py).
