@@ -636,7 +636,7 @@ def main():
         elif inflight:
             ev_note += "; TWO batches in flight and no serial leg (--no-serial-leg): the durations include the time the kernel waits for or shares the chip with the other batch's kernels"
         if q30:   # int8-MFMA blend: the matrix pipe is no longer the bound, the 153 MB basis + 41 MB output stream is
-            roof_decode = {"bound": "hbm", "kernel": "q_stage_kernel + decode_q_ring_kernel<16,4,8> (fr_decode_3dmm, Q30)",
+            roof_decode = {"bound": "hbm", "kernel": "q_stage_kernel + decode_q_ring_kernel<16,4,8,2,nt,%d,1> (fr_decode_render_forward_q30, phase 8)" % int(q30),
                            "achieved": ab["decode"] * B / (decode_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "traffic": None, "avg_ms": decode_ms, "algorithmic_bytes_per_launch": ab["decode"] * B}
         else:
@@ -699,7 +699,8 @@ def main():
                                          "(the f32-input MFMA and every other vector instruction of a SIMD take turns: r4t).  Round 5 "
                                          "tested that reading and it does NOT hold for the step: a decode with a third of the f32 "
                                          "kernel's vector-pipe time (Q30, ten int8 digit products; `q30_inflight`) moves the in-flight "
-                                         "step by 1-3 us, not by the 15 us of pipe time it frees, and a decode slimmed to co-reside "
+                                         "step by what its own DURATION changed (0.5-8 us depending on the box), not by the 17 us of "
+                                         "pipe time it frees, and a decode slimmed to co-reside "
                                          "with the other batch's emit workgroups makes it 9 us longer (profiles/round5_probes/r5b).  "
                                          "What binds the in-flight step is that each kernel fills every CU's registers / wave slots by "
                                          "itself -- the two batches alternate on a CU instead of sharing it -- and the ~385 MB a step "
@@ -762,7 +763,7 @@ def main():
                        "sharding": ("weak: every rank runs its own %d faces" % B if args.scaling == "weak" else
                                     "strong: ONE %d-face batch cut into contiguous shards (utils.dist.shard_range)" % args.batch)
                                    + ", no data-path collective",
-                       "decode_arith": "q30 (exact fixed point on the int8 MFMA)" if q30 else "f32 fmaf chain (f32-input MFMA)",
+                       "decode_arith": ("q30, %d digit-product levels (fixed point on the int8 MFMA, include/fr_hotpath.h)" % int(q30)) if q30 else "f32 fmaf chain (f32-input MFMA)",
                        "constants": "the packed basis (fr_decode_pack_basis) and the pre-validated triangle table "
                                     "(fr_decode_render_forward, phase 4) are built once per plan: both are "
                                     "tf.constants of the reference model (network.py:41-43, 178); a caller that repacks the "
