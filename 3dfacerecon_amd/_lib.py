@@ -234,7 +234,7 @@ def lib():
 DECODE_ARITH_Q30, DECODE_ARITH_F32 = 0, 1
 # This file is loaded under two module names (the package's `3dfacerecon_amd._lib`, and by path from the reference-style
 # flat modules rendering_layer/ops.py, nets/network.py, pipeline.py): process-wide choices live in ONE shared namespace.
-_STATE = sys.modules.setdefault("_fr_hotpath_state", types.SimpleNamespace(decode_arith=None, q30_levels=7))
+_STATE = sys.modules.setdefault("_fr_hotpath_state", types.SimpleNamespace(decode_arith=None, q30_levels=7, option_epoch=0))
 _ARITH_ENV = {"q30": 7, "q30l7": 7, "q30l5": 5, "q30l4": 4}
 
 
@@ -270,8 +270,15 @@ def set_decode_arith(mode, levels=None):
 
 
 def set_option(name, value):
-    """fr_set_option: a launcher knob by its FR_* name (the environment is only read once, at the first launch)."""
+    """fr_set_option: a launcher knob by its FR_* name (the environment is only read once, at the first launch).  Every
+    change bumps option_epoch(): host-side caches of what a launch left in a workspace (rendering_layer/ops.py: the packed
+    triangle table) are keyed on it, since some knobs decide whether and how that state is written."""
     check(lib().fr_set_option(name.encode(), int(value)), "fr_set_option(%s)" % name)
+    _STATE.option_epoch += 1
+
+
+def option_epoch():
+    return _STATE.option_epoch
 
 
 def get_option(name):

@@ -14,12 +14,12 @@ struct OptDesc {
 };
 const OptDesc kOpts[fr::OPT_COUNT] = {
     {"FR_DECODE_IMPL", 0, "loop"}, {"FR_DECODE_WIDE", 1, nullptr}, {"FR_DECODE_NBW", 0, nullptr},
-    {"FR_DECODE_WAVES", 16, nullptr}, {"FR_DECODE_NT", 1, nullptr}, {"FR_RESOLVE_OPT", 2, nullptr},
+    {"FR_DECODE_WAVES", 16, nullptr}, {"FR_DECODE_NT", -1, nullptr}, {"FR_RESOLVE_OPT", 2, nullptr},
     {"FR_EMIT_FILTER", 3, nullptr}, {"FR_RENDER_IMPL", 0, "scan"}, {"FR_RESOLVE_BLOCK", 0, nullptr},
     {"FR_RENDER_ROWS", 0, nullptr}, {"FR_DECODE_STORE", 0, nullptr},
     {"FR_FUSED_ORDER", 0, nullptr}, {"FR_FUSED_ALONE", 0, nullptr},
     {"FR_BWD_CHUNKS", 256, nullptr}, {"FR_BWD_CB", 0, nullptr}, {"FR_EMIT_ORDER", -1, nullptr},
-    {"FR_Q30_SCHED", 0, nullptr},
+    {"FR_Q30_SCHED", 0, nullptr}, {"FR_DECODE_WALK", 1, nullptr},
 };
 std::atomic<int> g_opt[fr::OPT_COUNT];
 std::once_flag g_opt_once;

@@ -85,15 +85,12 @@ __device__ __forceinline__ bool point_in_tri(const TriSetup& s, int x, int y) {
 // the entry points may be called from several host threads (the header says so); two threads racing here both set the same
 // attribute to the same value and both store 1 -- idempotent, and now also free of a data race in the C++ sense.
 typedef std::atomic<unsigned char> fr_lds_flags_t;
-// `dynamic_max`: the dynamic part's ceiling -- 160 KiB for kernels without static LDS arrays, less for a kernel that also declares
-// static ones (the attribute is refused when static + dynamic exceed the CU's 160 KiB).
-inline hipError_t fr_allow_full_lds(const void* kernel, fr_lds_flags_t* done /*[64], zero-initialised (static storage)*/,
-                                    int dynamic_max = 160 * 1024) {
+inline hipError_t fr_allow_full_lds(const void* kernel, fr_lds_flags_t* done /*[64], zero-initialised (static storage)*/) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
-    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dynamic_max);
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess && dev >= 0 && dev < 64) done[dev].store(1, std::memory_order_release);
     return e;
 }
@@ -106,7 +103,8 @@ enum Opt {
     OPT_DECODE_WIDE,    // FR_DECODE_WIDE    1 = 128-column passes for batches above 64 (default), 0 = off
     OPT_DECODE_NBW,     // FR_DECODE_NBW     0 = auto, 1 / 4 = column blocks per work item
     OPT_DECODE_WAVES,   // FR_DECODE_WAVES   16 (default) or 8 waves per decode workgroup
-    OPT_DECODE_NT,      // FR_DECODE_NT      1 = non-temporal basis stream (default), 0 = default cache policy
+    OPT_DECODE_NT,      // FR_DECODE_NT      -1 = by batch (default: non-temporal basis stream for passes of 64 faces, default cache policy
+                        //                   below), 1 = always non-temporal, 0 = always the default cache policy
     OPT_RESOLVE_OPT,    // FR_RESOLVE_OPT    2 = wave-local front for 256-thread bins (default), 1 = single-trip bins keep records in
                         //                   registers behind the block-wide list, 0 = two-pass resolver
     OPT_EMIT_FILTER,    // FR_EMIT_FILTER    bit 0: certified fp32 inside test, bit 1: single-pixel pre-cull (default 3)
@@ -121,6 +119,7 @@ enum Opt {
     OPT_EMIT_ORDER,     // FR_EMIT_ORDER     lane order of a segment's triangles: -1 scored per segment (default), 0 identity, 1 even / odd passes
     OPT_Q30_SCHED,      // FR_Q30_SCHED      Q30 streaming schedule: 0 = 8 waves x whole tiles, 16-deep ring (default) | 1 = 16 waves, 32-column
                         //                   halves on neighbouring waves, 8-deep ring
+    OPT_DECODE_WALK,    // FR_DECODE_WALK    1 = the last, partial round of tiles dealt evenly over the CUs (default), 0 = round-robin pairs
     OPT_COUNT
 };
 int opt(Opt o);

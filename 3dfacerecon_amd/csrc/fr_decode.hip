@@ -315,11 +315,18 @@ struct NoProbe {
 
 template <int R>
 __device__ __forceinline__ void ring_wait(f32x4& slot) {
-    static_assert(R == 6 || R == 8, "ring size");  // (12 slots were measured too: slower, and they spill)
-    if constexpr (R == 6) asm volatile("s_waitcnt vmcnt(5)" : "+v"(slot));
+    static_assert(R == 4 || R == 6 || R == 8, "ring size");  // (12 slots were measured too: slower, and they spill)
+    if constexpr (R == 4) asm volatile("s_waitcnt vmcnt(3)" : "+v"(slot));
+    else if constexpr (R == 6) asm volatile("s_waitcnt vmcnt(5)" : "+v"(slot));
     else asm volatile("s_waitcnt vmcnt(7)" : "+v"(slot));
 }
-
+// (Round 6, measured and rejected -- profiles/round6_probes/r6a: on gfx950 stores count in vmcnt with the loads, in issue
+// order, so behind an epilogue of six store instructions vmcnt(R-1) on fragments 2 .. R-1 of the NEXT item waits for the
+// acknowledgement of those stores, not for the fragment.  "Store-aware" waits -- vmcnt(R-1+6) on the first R fragments of
+// every item but a wave's first -- keep the ring R deep across the epilogue and make the kernel SLOWER when the basis comes
+// from HBM: 57.1 against 54.0 us behind a 512 MiB flush, 55.0 against 52.2 back to back, 45.0 against 44.4 with the basis
+// resident in the Infinity Cache; in the bench 56.6 against 54.4 us.  The accidental pause after every epilogue is a
+// throttle the memory side likes: fewer requests in flight while the stores drain.)
 // WPE: waves per SIMD the register allocation is sized for (>= DEC_WAVES / 4).  A workgroup of fewer waves than that
 // leaves VGPRs free on purpose: the 8-wave form (WPE = 4: <= 128 VGPRs, half the register file) lets the render
 // kernels of the previous batch share the CU with the decode of the next one (pipeline.py, PipelinedPlan).
@@ -359,8 +366,9 @@ void decode_ring_kernel(DecodeArgs a) {
     const int slots = DEC_WAVES / H2;
     const int slot = wave / H2;
     const int hf = wave - slot * H2;
-    const TileWalk tw = tile_walk(slot, slots, (int)blockIdx.x, (int)gridDim.x);
-    const int tile0 = tw.first, tstride = tw.stride;
+    const ItemWalk tw = item_walk(a.walk, slot, slots, (int)blockIdx.x, (int)gridDim.x, tiles);
+    const int n_items = tw.items();
+    const int tile0 = n_items ? tw.tile0() : tiles;   // (tiles = "no work", as before)
     const float* Pll = smem + (size_t)hf * half_floats;
     int sw[4];
     lane_swizzle<NBW>(lane, sw);
@@ -423,9 +431,11 @@ void decode_ring_kernel(DecodeArgs a) {
     // live k-steps (of 4) in the last shape / expression group
     const int ks_s = GS > 0 ? (a.ns - KGROUP * (GS - 1) + 3) / 4 : 4;
     const int ks_e = GE > 0 ? (a.ne - KGROUP * (GE - 1) + 3) / 4 : 4;
-    for (int ct = tile0; ct < tiles; ct += tstride) {
-        int nt = ct + tstride;  // tile whose fragments are requested once this item's run out
-        if (nt >= tiles) nt = tile0;  // past the end: harmless re-request of a valid address, never consumed
+    int ct = tile0;
+    for (int it = 0; it < n_items; it++) {
+        // tile whose fragments are requested once this item's run out (past the end: harmless re-request of a valid
+        // address, never consumed)
+        const int nt = tw.next(it, ct, n_items, tile0);
         typename BFrag<NBW>::type bq[4];
         pr.item_begin();
 #pragma unroll
@@ -484,6 +494,7 @@ void decode_ring_kernel(DecodeArgs a) {
             else decode_store<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
         }
         pr.item_end();
+        ct = nt;
 #pragma unroll
         for (int cc = 0; cc < 3; cc++)
 #pragma unroll
@@ -603,11 +614,12 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
     a.B = B; a.N = N; a.ns = n_shape; a.ne = n_exp;
     a.im_size = im_size;
     a.pitch = pitch;
+    a.walk = opt(OPT_DECODE_WALK);
     const int cus = fr_device_cu_count();
     const bool loop_env = opt(OPT_DECODE_IMPL) == 1;
     const bool wide_off = opt(OPT_DECODE_WIDE) == 0;
     const int nbw_env = opt(OPT_DECODE_NBW), waves_env = opt(OPT_DECODE_WAVES);
-    const bool nt_off = opt(OPT_DECODE_NT) == 0;
+    const int nt_opt = opt(OPT_DECODE_NT);
     const bool ring_shape = !loop_env && groups_of(n_shape) == 13 && groups_of(n_exp) == 2;
     // 128 columns per pass (64-column items on 12 waves) when more than 64 remain: the basis is streamed once per 128
     // faces instead of once per 64 (102 vs 110 us at B = 128; FR_DECODE_WIDE=0 turns it off)
@@ -631,8 +643,12 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
         int rc;
         if (ring && nbw == 1) rc = launch_decode_ring<13, 2, 8, 1, 16, 64, 4, true>(a, lds, cus, tiles, stream);
         else if (ring && waves_env == 8) rc = launch_decode_ring<13, 2, 8, 2, 8, 64, 4>(a, lds, cus, tiles, stream);
-        else if (ring && nt_off)
-            rc = launch_decode_ring<13, 2, 8, 2, 16>(a, lds, cus, tiles, stream);  // A/B knob: default-policy basis loads
+        else if (ring && (nt_opt == 0 || (nt_opt < 0 && B - b0 < MAXB)))
+            // default cache policy for the basis stream of a pass below 64 faces: its working set (153 MB of basis + 3.7 MB of
+            // vertices, records and planes per face) leaves the basis a share of the 256 MiB Infinity Cache worth having --
+            // one batch at a time +4.1 % at 32 faces and +2.0 % at 48, two in flight +3.1 % at 48, nothing either way at 16
+            // (profiles/round6_probes/r6a); at 64 faces the non-temporal hint below wins (r2f, r5m)
+            rc = launch_decode_ring<13, 2, 8, 2, 16, 64, 4, false, true>(a, lds, cus, tiles, stream);
         else if (ring && opt(OPT_DECODE_STORE) == 1)
             rc = launch_decode_ring<13, 2, 8, 2, 16, 64, 4, true, true, true>(a, lds, cus, tiles, stream);  // A/B knob: transposed accumulators
         else if (ring)

@@ -936,9 +936,6 @@ __device__ __forceinline__ void resolve_body(const RenderArgs& a, const int bin,
     static_assert(!LEAN || BLOCK == LEAN_BLOCK, "the lean resolver is a 256-thread bin");
     constexpr int CAP = LEAN ? LEAN_SLOT_CAP : SLOT_CAP;
     const int tid = threadIdx.x;
-#ifdef FR_FUSED_PROBE   // tools/fused_probe2.py: the resolve role as a no-op (build the library with -DFR_FUSED_PROBE)
-    if (LEAN && (a.resolve_opt & 8)) return;
-#endif
     const int b = bin / a.strips;
     const int s = bin - b * a.strips;
     const int r0 = s * a.rows;
@@ -1100,9 +1097,6 @@ __device__ __forceinline__ void resolve_body(const RenderArgs& a, const int bin,
                     }
                 }
                 pr.template stamp<5>();   // winners' normals stored
-#ifdef FR_FUSED_PROBE   // ... and without its plane writer
-                if (LEAN && (a.resolve_opt & 16)) return;
-#endif
                 if (FUSED)
                     write_strip_fused<BLOCK>(a, b, r0, npix, keys);
                 else

@@ -105,18 +105,26 @@ def _workspace(dev, nbytes):
 
 
 def _render_phases(ent, cached, tri_c, geom):
-    """7 (pack + emit + resolve) or 3 when the entry's triangle table was packed from this very list for this geometry."""
+    """-> (phases, pending): phases = 7 (pack + emit + resolve), or 3 when the entry's triangle table was packed from this very
+    list for this geometry under the launcher options in force now; `pending` is the record _table_packed() commits once the
+    call that packs the table has RETURNED 0 (a failed or unsupported call leaves no claim about the table behind)."""
     # an inference tensor (created under torch.inference_mode()) has no version counter: in-place writes to it cannot be
     # seen, so its table is never reused -- packed every call, like a caller that passes a new tensor each time
     if tri_c.is_inference():
         ent.tri_ref = ent.tri_key = None
-        return 7
-    key = (tri_c._version, tri_c.data_ptr()) + geom
+        return 7, None
+    # (the option epoch: FR_RENDER_IMPL / FR_RENDER_ROWS / FR_EMIT_ORDER decide whether and how the table is written, and
+    # can only change through _lib.set_option, which bumps it)
+    key = (tri_c._version, tri_c.data_ptr(), _host().option_epoch()) + geom
     if cached and ent.tri_ref is not None and ent.tri_ref() is tri_c and ent.tri_key == key:
-        return 3
-    ent.tri_ref = weakref.ref(tri_c) if cached else None
-    ent.tri_key = key if cached else None
-    return 7
+        return 3, None
+    ent.tri_ref = ent.tri_key = None   # whatever this call does, the old record no longer describes the table
+    return 7, ((weakref.ref(tri_c), key) if cached else None)
+
+
+def _table_packed(ent, pending):
+    if pending is not None:
+        ent.tri_ref, ent.tri_key = pending
 
 
 def _check_forward_shapes(ver, tri, texture, image):
@@ -176,10 +184,12 @@ class _RenderDepth(torch.autograd.Function):
             ws_bytes = L.fr_render_depth_workspace_bytes(B, nver, ntri, H, W)
             if ws_bytes:
                 ent, cached = _workspace(dev, ws_bytes)
-                phases = _render_phases(ent, cached, tri_c, (B, nver, ntri, H, W))
+                phases, pending = _render_phases(ent, cached, tri_c, (B, nver, ntri, H, W))
                 rc = L.fr_render_depth_forward_phases(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), B, nver, ntri, H, W, 3,
                                                       tex_batch, h.ptr(depth), h.ptr(tex_img), h.ptr(normal), h.ptr(tri_ind),
                                                       h.ptr(ent.buf), ws_bytes, h.stream_ptr(dev), phases)
+                if rc == 0:
+                    _table_packed(ent, pending)
             else:
                 rc = L.fr_render_depth_forward(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), B, nver, ntri, H, W, 3, tex_batch,
                                                h.ptr(depth), h.ptr(tex_img), h.ptr(normal), h.ptr(tri_ind), None, 0,
@@ -235,13 +245,14 @@ class _RenderingLayerFused(torch.autograd.Function):
             ws_bytes = L.fr_render_depth_workspace_bytes(B, nver, ntri, H, W)
             ent, cached = _workspace(dev, ws_bytes)
             # the same "pack once while the same `tri` tensor is passed" rule as render_depth (the table is the same table)
-            phases = _render_phases(ent, cached, tri_c, (B, nver, ntri, H, W))
+            phases, pending = _render_phases(ent, cached, tri_c, (B, nver, ntri, H, W))
             rc = L.fr_rendering_layer_forward_phases(h.ptr(ver_c), h.ptr(tri_c), h.ptr(tex_c), h.ptr(img_c), B, nver, ntri, H, W,
                                                      tex_batch, h.ptr(net_in), h.ptr(depth_img), h.ptr(depth), h.ptr(tri_ind),
                                                      h.ptr(ent.buf), ws_bytes, h.stream_ptr(dev), phases)
         if rc == -4:
             raise NotImplementedError("fused rendering layer: shape only covered by the fallback rasteriser")
         h.check(rc, "fr_rendering_layer_forward")
+        _table_packed(ent, pending)
         ctx.save_for_backward(tri_c, tri_ind, depth, img_c)
         ctx.dims = (B, nver, ntri, H, W)
         ctx.mark_non_differentiable(tri_ind)

@@ -132,7 +132,8 @@ def test_zero_focal_column(oracle, synth):
 def test_packed_and_reference_layout_entry_points(oracle, synth):
     """fr_decode_3dmm_backward (basis in its reference layout, no extra memory: prepass + GEMM + reduce),
     fr_decode_3dmm_backward_packed (packed image, ONE fused kernel + reduce) and fr_decode_3dmm_backward_packed_mu (the same
-    kernel with d f formed from mu instead of the forward's output: the one the autograd node uses since round 5) are the same
+    kernel with d f formed from mu instead of the forward's output: what the autograd node calls when `basis.backward_from_mu` is set
+    -- off by default, it saves 41 MB per decode and no time, nets/network.py::_Decode3DMM) are the same
     gradient with differently ordered -- each fixed -- partial sums: both within tolerance of the float64 gradient, each
     bit-reproducible, at a ragged shape (N = 187: the last vertex group is 11 vertices; 217 coefficients: 13 + 2 blocks, the
     last wave has one live), at the model's 199 + 29 with 70 faces (two passes) and at a one-block basis (staging-only waves)."""

@@ -96,7 +96,7 @@ def test_fused_layer_packs_the_triangle_list_once(full_assets, synth):
         first = o.rendering_layer_fused(V, net.tri, net.vertex_code, im)
         again = o.rendering_layer_fused(V, net.tri, net.vertex_code, im)
         plain = o.render_depth(V, net.tri, net.vertex_code, im.expand(-1, -1, -1, 3))      # the table serves the plain op too
-        assert seen == [7, 3, 3]
+        assert [ph for ph, _ in seen] == [7, 3, 3]
         for a, b in zip(first, again):
             assert torch.equal(a, b)
         assert torch.equal(plain[0], first[2]) and torch.equal(plain[3], first[3])
@@ -105,8 +105,37 @@ def test_fused_layer_packs_the_triangle_list_once(full_assets, synth):
         moved = o.rendering_layer_fused(V, tri2, net.vertex_code, im)
         tri2[:, :10] = net.tri[:, :10]                      # written in place (version counter) -> packed again
         back = o.rendering_layer_fused(V, tri2, net.vertex_code, im)
-        assert seen[3:] == [7, 7]
+        assert [ph for ph, _ in seen[3:]] == [7, 7]
         assert not torch.equal(moved[3], first[3]) and torch.equal(back[3], first[3])
+        # a launcher option that decides how the table is written invalidates the record (option epoch) ...
+        h = o._host()
+        with h.options(FR_EMIT_ORDER=0):
+            other = o.rendering_layer_fused(V, tri2, net.vertex_code, im)
+        restored = o.rendering_layer_fused(V, tri2, net.vertex_code, im)
+        assert [ph for ph, _ in seen[5:]] == [7, 7]
+        for a, b in zip(other, back):
+            assert torch.equal(a, b)
+        for a, b in zip(restored, back):
+            assert torch.equal(a, b)
+        # ... and a call that FAILS leaves no claim about the table behind: the next good call packs again
+        bad = V[:, :, :-1].contiguous()   # nver differs from the texture's: refused before any launch
+        with pytest.raises(ValueError):
+            o.rendering_layer_fused(bad, tri2, net.vertex_code, im)
+        o.clear_workspace_cache()
+        real_call = h.lib().fr_rendering_layer_forward_phases
+        try:
+            h.lib().fr_rendering_layer_forward_phases = lambda *a: -3     # the pack call "fails"
+            with pytest.raises(RuntimeError):
+                o.rendering_layer_fused(V, tri2, net.vertex_code, im)
+        finally:
+            h.lib().fr_rendering_layer_forward_phases = real_call
+        assert seen[-1][0] == 7 and seen[-1][1] is not None
+        ent = next(iter(o._WS_CACHE.values()))
+        assert ent.tri_ref is None and ent.tri_key is None
+        after = o.rendering_layer_fused(V, tri2, net.vertex_code, im)
+        assert seen[-1][0] == 7
+        for a, b in zip(after, back):
+            assert torch.equal(a, b)
     finally:
         o._render_phases = real
         o.clear_workspace_cache()

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <map>
 #include <stdio.h>
+#include <type_traits>
 #include <vector>
 
 namespace fr { int opt(Opt) { return 0; } }   // the launcher of the included TU is not used here
@@ -97,15 +98,20 @@ struct Ctx {
 };
 
 static int g_prio = 1;
-template <bool NT, class PR, bool PRIO>
+static int g_ring = 8;   // fragment-ring depth (8 = the product; 6 and 4 only for the unablated, unstamped kernel with priorities)
+template <bool NT, class PR, bool PRIO, int R = 8>
 static void launch_t(const Ctx& c) {
-    auto k = fr::decode_ring_kernel<13, 2, 8, 2, 16, 64, 4, NT, PR, PRIO>;
+    auto k = fr::decode_ring_kernel<13, 2, R, 2, 16, 64, 4, NT, PR, PRIO>;
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
     hipLaunchKernelGGL(k, dim3(c.grid), dim3(1024), c.lds, c.st, c.a);
 }
 template <bool NT, class PR>
 static void launch(const Ctx& c) {
+    if constexpr (std::is_same<PR, AblateProbe<0>>::value) {
+        if (g_prio && g_ring == 6) return launch_t<NT, PR, true, 6>(c);
+        if (g_prio && g_ring == 4) return launch_t<NT, PR, true, 4>(c);
+    }
     if (g_prio) launch_t<NT, PR, true>(c);
     else launch_t<NT, PR, false>(c);
 }
@@ -160,6 +166,9 @@ static void stamped(const Ctx& c, bool flush, const char* name, unsigned long lo
     for (int i = 0; i < 6000; i++) launch<NT, AblateProbe<BITS>>(c);
     (void)hipStreamSynchronize(c.st);
     std::vector<double> clk_all, dur_all, prol_all, prime_all, util_all, ramp_all, tail_all, win_all, item_all, store_all, lastmid_all;
+    // by XCD (all repetitions pooled): items per SIMD, item window, utilisation, first item's start and the last wave's exit
+    // after the kernel's first wave started (realtime stamps: comparable across XCDs, 10 ns resolution)
+    std::vector<double> x_items[16], x_win[16], x_util[16], x_exit[16], x_first[16], x_clk[16];
     double items_total = 0;
     for (int rep = 0; rep < 5; rep++) {
         (void)hipMemsetAsync(dstamps, 0, h.size() * 8, c.st);
@@ -184,6 +193,9 @@ static void stamped(const Ctx& c, bool flush, const char* name, unsigned long lo
             if (!o[14]) continue;
             const double ticks = (double)(o[9] - o[0]), rt = (double)(o[10] - o[1]);
             if (rt > 100) clk.push_back(ticks / rt * 0.1);  // GHz: memtime ticks per 10 ns
+            if (rt > 100) x_clk[o[12] & 0xF].push_back(ticks / rt * 0.1);
+            x_exit[o[12] & 0xF].push_back((double)(o[10] - r0) * 0.01);
+            if (o[7] && rt > 100) x_first[o[12] & 0xF].push_back((double)(o[1] - r0) * 0.01 + (double)(o[4] - o[0]) / (ticks / rt * 0.1) * 1e-3);
             simd[((o[12] & 0xF) << 32) | ((o[11] >> 4) & 0xFFF3)].push_back(w);  // cu/sh/se bits 8.. + simd bits 5:4 -> after >>4: bits 0,1 = simd
             ramp_all.push_back((double)(o[1] - r0) * 0.01);
             tail_all.push_back((double)(r1 - o[10]) * 0.01);
@@ -209,6 +221,10 @@ static void stamped(const Ctx& c, bool flush, const char* name, unsigned long lo
             const double window = (double)(lastmid - first);
             util_all.push_back(items * 348.0 * 32.0 / window);
             win_all.push_back(window);
+            const int xc = (int)((kv.first >> 32) & 0xF);
+            x_items[xc].push_back(items);
+            x_win[xc].push_back(window);
+            x_util[xc].push_back(items * 348.0 * 32.0 / window);
             lastmid_all.push_back((double)(t9 - lastmid));
         }
     }
@@ -226,16 +242,34 @@ static void stamped(const Ctx& c, bool flush, const char* name, unsigned long lo
            med(win_all) / clk * 1e-3, vmax(win_all) / clk * 1e-3);
     printf("     \"matrix_pipe_utilisation_inside_window\": {\"median\": %.3f, \"min\": %.3f, \"max\": %.3f},\n", med(util_all), vmin(util_all), vmax(util_all));
     printf("     \"simd_last_mfma_to_last_wave_exit_cycles\": {\"median\": %.0f, \"max\": %.0f},\n", med(lastmid_all), vmax(lastmid_all));
+    printf("     \"by_xcd\": [\n");
+    {
+        int lastx = -1;
+        for (int xc = 0; xc < 16; xc++) if (!x_items[xc].empty()) lastx = xc;
+        for (int xc = 0; xc <= lastx; xc++) {
+            if (x_items[xc].empty()) continue;
+            double isum = 0;
+            for (double v : x_items[xc]) isum += v;
+            const double ck = med(x_clk[xc]);
+            printf("       {\"xcd\": %d, \"simds\": %zu, \"items_per_simd\": %.2f, \"clock_GHz\": %.3f, \"first_item_begin_us\": {\"median\": %.2f, \"max\": %.2f}, "
+                   "\"window_us\": {\"median\": %.2f, \"max\": %.2f}, \"utilisation\": {\"median\": %.3f, \"min\": %.3f}, \"wave_exit_us\": {\"median\": %.2f, \"max\": %.2f}}%s\n",
+                   xc, x_items[xc].size() / 5, isum / x_items[xc].size(), ck, med(x_first[xc]), vmax(x_first[xc]), med(x_win[xc]) / ck * 1e-3,
+                   vmax(x_win[xc]) / ck * 1e-3, med(x_util[xc]), vmin(x_util[xc]), med(x_exit[xc]), vmax(x_exit[xc]), xc == lastx ? "" : ",");
+        }
+    }
+    printf("     ],\n");
     printf("     \"wave_exit_before_kernel_end_us\": {\"median\": %.2f, \"max\": %.2f}}%s\n", med(tail_all), vmax(tail_all), last ? "" : ",");
 }
 
 int main(int argc, char** argv) {
     using namespace fr;
-    // decode_probe [B] [N] [pitched rows 0|1] [quick 0|1] [wave priorities 0|1]
+    // decode_probe [B] [N] [pitched rows 0|1] [quick 0|1|2 (2 = tile-walk / ring-depth / priority A/B + stamps by XCD of both walks)] [wave priorities 0|1] [pitch/prio A/B 0|1] [walk 0|1]
     const int B = argc > 1 ? atoi(argv[1]) : 64, N = argc > 2 ? atoi(argv[2]) : 53215, ns = 199, ne = 29;
     const int pitched = argc > 3 ? atoi(argv[3]) : 1;
-    const bool quick = argc > 4 && atoi(argv[4]);
+    const bool quick = argc > 4 && atoi(argv[4]) == 1;
+    const bool saw_ab = argc > 4 && atoi(argv[4]) == 2;
     g_prio = argc > 5 ? atoi(argv[5]) : 1;
+    const int walk_arg = argc > 7 ? atoi(argv[7]) : 1;
     const size_t pb = fr_packed_basis_bytes(N, ns, ne);
     void *packed, *params, *out, *flush;
     unsigned long long* dstamps;
@@ -259,9 +293,9 @@ int main(int argc, char** argv) {
     c.a.mu_p = (const float*)(c.a.A + tiles * G * 3 * 64);
     c.a.R_override = nullptr;
     c.a.out = (float*)out;
-    c.a.B = B; c.a.N = N; c.a.ns = ns; c.a.ne = ne; c.a.b0 = 0; c.a.halves = 2; c.a.im_size = 200.f; c.a.pitch = pitched ? (N + 31) & ~31 : N;
+    c.a.B = B; c.a.N = N; c.a.ns = ns; c.a.ne = ne; c.a.b0 = 0; c.a.halves = B > 32 ? 2 : 1; c.a.walk = walk_arg; c.a.im_size = 200.f; c.a.pitch = pitched ? (N + 31) & ~31 : N;
     c.lds = G * KGROUP * 16 * sizeof(float4) + 64 * 12 * sizeof(float) + 64 * 3 * 2 * sizeof(double);
-    c.grid = std::min(fr_device_cu_count(), (int)((tiles + 7) / 8));
+    c.grid = std::min(fr_device_cu_count(), (int)((tiles + 16 / c.a.halves - 1) / (16 / c.a.halves)));
     c.st = 0;
     c.flush = flush;
     c.flush_bytes = flush_bytes;
@@ -287,6 +321,35 @@ int main(int argc, char** argv) {
     printf("{\"device\": \"%s\", \"cus\": %d, \"B\": %d, \"N\": %d, \"row_pitch\": %d, \"wave_priorities\": %d, \"items\": %zu, \"mfma_per_item\": 348,\n", prop.gcnArchName, c.grid, B, N, c.a.pitch, g_prio, tiles * 2);
     printf(" \"mfma_floor_us_at_2.4GHz\": {\"average_6.5_items_per_simd\": %.2f, \"worst_simd_7_items\": %.2f},\n",
            tiles * 2 * 348.0 * 32.0 / 1024.0 / 2.4e3, 7 * 348.0 * 32.0 / 2.4e3);
+    if (saw_ab) {   // interleaved A/B in one process: tile walk x basis policy, ring depth, wave priorities; then the stamps of both walks
+        struct V { const char* name; int walk, ring, prio; };
+        const V vs[] = {{"walk=0 ring=8 prio=1 (round 5)", 0, 8, 1}, {"walk=1 ring=8 prio=1", 1, 8, 1}, {"walk=1 ring=6 prio=1", 1, 6, 1},
+                        {"walk=1 ring=4 prio=1", 1, 4, 1}, {"walk=1 ring=8 prio=0", 1, 8, 0}};
+        const int nv = sizeof(vs) / sizeof(vs[0]);
+        printf(" \"ab_us\": {\n");
+        std::vector<double> r[8][4];
+        for (int round = 0; round < 5; round++)
+            for (int v = 0; v < nv; v++) {
+                c.a.walk = vs[v].walk; g_ring = vs[v].ring; g_prio = vs[v].prio;
+                r[v][0].push_back(time_us<true, AblateProbe<0>>(c, true, 9));
+                r[v][1].push_back(time_b2b_us<true, AblateProbe<0>>(c, 200));
+                r[v][2].push_back(time_us<false, AblateProbe<0>>(c, true, 9));
+                r[v][3].push_back(time_b2b_us<false, AblateProbe<0>>(c, 200));
+            }
+        for (int v = 0; v < nv; v++)
+            printf("  \"%s\": {\"nt_after_512MiB_flush\": {\"median\": %.2f, \"min\": %.2f, \"max\": %.2f}, \"nt_back_to_back\": {\"median\": %.2f, \"min\": %.2f}, "
+                   "\"cached_after_512MiB_flush\": {\"median\": %.2f, \"min\": %.2f}, \"cached_back_to_back\": {\"median\": %.2f, \"min\": %.2f}}%s\n", vs[v].name,
+                   med(r[v][0]), vmin(r[v][0]), vmax(r[v][0]), med(r[v][1]), vmin(r[v][1]), med(r[v][2]), vmin(r[v][2]), med(r[v][3]), vmin(r[v][3]), v == nv - 1 ? "" : ",");
+        printf(" },\n \"stamps\": [\n");
+        g_ring = 8; g_prio = 1;
+        c.a.walk = 0;
+        stamped<true, 0>(c, true, "round-robin walk (round 5), nt basis from HBM", dstamps, false);
+        c.a.walk = 1;
+        stamped<true, 0>(c, true, "balanced walk, nt basis from HBM", dstamps, false);
+        stamped<false, 0>(c, false, "balanced walk, default-policy basis back to back (Infinity-Cache resident)", dstamps, true);
+        printf(" ]}\n");
+        return 0;
+    }
     printf(" \"timing_us\": {\n");
 #define ROW(name, PR)                                                                                                   \
     printf("  \"%s\": {\"nt_back_to_back\": %.1f, \"nt_event_single\": %.1f, \"nt_after_512MiB_flush\": %.1f, "     \
