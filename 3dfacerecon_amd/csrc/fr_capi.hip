@@ -19,7 +19,7 @@ const OptDesc kOpts[fr::OPT_COUNT] = {
     {"FR_RENDER_ROWS", 0, nullptr}, {"FR_DECODE_STORE", 0, nullptr},
     {"FR_FUSED_ORDER", 0, nullptr}, {"FR_FUSED_ALONE", 0, nullptr},
     {"FR_BWD_CHUNKS", 256, nullptr}, {"FR_BWD_CB", 0, nullptr}, {"FR_EMIT_ORDER", -1, nullptr},
-    {"FR_Q30_SCHED", 0, nullptr}, {"FR_DECODE_WALK", 1, nullptr},
+    {"FR_Q30_SCHED", 0, nullptr},
 };
 std::atomic<int> g_opt[fr::OPT_COUNT];
 std::once_flag g_opt_once;

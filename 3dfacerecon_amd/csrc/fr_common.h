@@ -119,7 +119,6 @@ enum Opt {
     OPT_EMIT_ORDER,     // FR_EMIT_ORDER     lane order of a segment's triangles: -1 scored per segment (default), 0 identity, 1 even / odd passes
     OPT_Q30_SCHED,      // FR_Q30_SCHED      Q30 streaming schedule: 0 = 8 waves x whole tiles, 16-deep ring (default) | 1 = 16 waves, 32-column
                         //                   halves on neighbouring waves, 8-deep ring
-    OPT_DECODE_WALK,    // FR_DECODE_WALK    1 = the last, partial round of tiles dealt evenly over the CUs (default), 0 = round-robin pairs
     OPT_COUNT
 };
 int opt(Opt o);

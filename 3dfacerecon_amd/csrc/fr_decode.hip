@@ -366,9 +366,8 @@ void decode_ring_kernel(DecodeArgs a) {
     const int slots = DEC_WAVES / H2;
     const int slot = wave / H2;
     const int hf = wave - slot * H2;
-    const ItemWalk tw = item_walk(a.walk, slot, slots, (int)blockIdx.x, (int)gridDim.x, tiles);
-    const int n_items = tw.items();
-    const int tile0 = n_items ? tw.tile0() : tiles;   // (tiles = "no work", as before)
+    const TileWalk tw = tile_walk(slot, slots, (int)blockIdx.x, (int)gridDim.x);
+    const int tile0 = tw.first, tstride = tw.stride;
     const float* Pll = smem + (size_t)hf * half_floats;
     int sw[4];
     lane_swizzle<NBW>(lane, sw);
@@ -431,11 +430,9 @@ void decode_ring_kernel(DecodeArgs a) {
     // live k-steps (of 4) in the last shape / expression group
     const int ks_s = GS > 0 ? (a.ns - KGROUP * (GS - 1) + 3) / 4 : 4;
     const int ks_e = GE > 0 ? (a.ne - KGROUP * (GE - 1) + 3) / 4 : 4;
-    int ct = tile0;
-    for (int it = 0; it < n_items; it++) {
-        // tile whose fragments are requested once this item's run out (past the end: harmless re-request of a valid
-        // address, never consumed)
-        const int nt = tw.next(it, ct, n_items, tile0);
+    for (int ct = tile0; ct < tiles; ct += tstride) {
+        int nt = ct + tstride;  // tile whose fragments are requested once this item's run out
+        if (nt >= tiles) nt = tile0;  // past the end: harmless re-request of a valid address, never consumed
         typename BFrag<NBW>::type bq[4];
         pr.item_begin();
 #pragma unroll
@@ -494,7 +491,6 @@ void decode_ring_kernel(DecodeArgs a) {
             else decode_store<NBW>(a, c[0], c[1], c[2], Mt, ct, hf, lane, nbatch, N);
         }
         pr.item_end();
-        ct = nt;
 #pragma unroll
         for (int cc = 0; cc < 3; cc++)
 #pragma unroll
@@ -614,7 +610,6 @@ int fr_launch_decode(const float* params, const void* packed, const float* R_ove
     a.B = B; a.N = N; a.ns = n_shape; a.ne = n_exp;
     a.im_size = im_size;
     a.pitch = pitch;
-    a.walk = opt(OPT_DECODE_WALK);
     const int cus = fr_device_cu_count();
     const bool loop_env = opt(OPT_DECODE_IMPL) == 1;
     const bool wide_off = opt(OPT_DECODE_WIDE) == 0;

@@ -456,9 +456,8 @@ void decode_q_ring_kernel(DecodeQArgs a) {
     const int tiles = tiles_of(a.d.N);
     const int N = a.d.N;
     const int slot = wave / H2, hf = wave - slot * H2;
-    const ItemWalk tw = item_walk(a.d.walk, slot, DEC_WAVES / H2, (int)blockIdx.x, (int)gridDim.x, tiles);
-    const int n_items = tw.items();
-    const int tile0 = n_items ? tw.tile0() : tiles;   // (tiles = "no work")
+    const TileWalk tw = tile_walk(slot, DEC_WAVES / H2, (int)blockIdx.x, (int)gridDim.x);
+    const int tile0 = tw.first, tstride = tw.stride;
     const unsigned voffA = (unsigned)lane * 16u;
     const char* Tb = a.tiles;
 
@@ -486,9 +485,9 @@ void decode_q_ring_kernel(DecodeQArgs a) {
     f32x4* park_w = park_s + (size_t)wave * 2 * NBW * 64 + lane;
     const char* Bl = Bimg + (size_t)(hf * NBW) * 1024 + (size_t)lane * 16;
 
-    int ct = tile0;
-    for (int it = 0; it < n_items; it++, ct = tw.next(it - 1, ct, n_items, tile0)) {
-        const int nt = tw.next(it, ct, n_items, tile0);   // past the end: harmless re-request of a valid address, never consumed
+    for (int ct = tile0; ct < tiles; ct += tstride) {
+        int nt = ct + tstride;
+        if (nt >= tiles) nt = tile0;   // past the end: harmless re-request of a valid address, never consumed
         i32x4 acc[LV][NBW];
 #pragma unroll
         for (int g = 0; g < F / 4; g++) {
@@ -676,7 +675,6 @@ int fr_launch_decode_q(const float* params, const void* qimage, const float* R_o
     a.d.halves = 1;
     a.d.im_size = im_size;
     a.d.pitch = pitch;
-    a.d.walk = opt(OPT_DECODE_WALK);
     const size_t lds = q_stage_bytes(a.qs.S);
     if (lds > 160 * 1024) return FR_ERR_UNSUPPORTED;
     if (!workspace || ws_bytes < lds || ((uintptr_t)workspace & 15)) return FR_ERR_WORKSPACE;

@@ -22,7 +22,6 @@ struct DecodeArgs {
     int b0;                   // first batch column of this pass
     int halves;               // column-block groups per tile: a work item is (tile, half)
     float im_size;
-    int walk;                 // streaming kernels: 0 = tile_walk (round-robin pairs), 1 = tile_walk_balanced (FR_DECODE_WALK)
     int pitch;                // floats between consecutive coordinate rows of `out` (>= N; N for the dense [B,3,N] tensor of
                               // the op surface; the fused decode -> render entry point pads it to a multiple of 32 so that
                               // every 16-vertex tile piece is an aligned 64-byte half of a 128-byte line)
@@ -57,7 +56,7 @@ __device__ __forceinline__ void rotation_from_sincos(double sp, double cp, doubl
 struct TileWalk {
     int first, stride;
 };
-__host__ __device__ __forceinline__ TileWalk tile_walk(int slot, int slots, int b, int grid) {
+__device__ __forceinline__ TileWalk tile_walk(int slot, int slots, int b, int grid) {
     const int pb = (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b;
     TileWalk w;
     if (slots & 1) {  // odd slot count (not used by the launchers): plain round-robin over tiles
@@ -70,51 +69,13 @@ __host__ __device__ __forceinline__ TileWalk tile_walk(int slot, int slots, int 
     return w;
 }
 
-// The item list of one slot for the streaming kernels: `n_regular` tiles at first, first + stride, ..., then `extra` (>= 0) once.
-struct ItemWalk {
-    int first, stride, n_regular, extra;
-    __host__ __device__ __forceinline__ int items() const { return n_regular + (extra >= 0 ? 1 : 0); }
-    __host__ __device__ __forceinline__ int tile0() const { return n_regular > 0 ? first : extra; }   // -1: the slot has no work
-    // the tile after item `it` (which is tile `ct`); behind the last item: `wrap` (a valid tile, requested and never consumed)
-    __host__ __device__ __forceinline__ int next(int it, int ct, int n_items, int wrap) const {
-        return it + 1 < n_regular ? ct + stride : (it + 1 < n_items ? extra : wrap);
-    }
-};
-// tile_walk as an item list (every round dealt round-robin: with 3,326 tiles on 256 CUs x 8 slots the second, partial round
-// gives the CUs of XCDs 0-3 three more tile pairs and those of XCDs 4-7 two -- 28 against 24 half-tile items per CU, and the
-// stamped kernel shows XCDs 4-7 idle for the last 6 us of the launch: profiles/round6_probes/r6a).
-__host__ __device__ __forceinline__ ItemWalk item_walk_round_robin(int slot, int slots, int b, int grid, int tiles) {
-    const TileWalk t = tile_walk(slot, slots, b, grid);
-    ItemWalk w;
-    w.first = t.first;
-    w.stride = t.stride;
-    w.n_regular = t.first < tiles ? (tiles - 1 - t.first) / t.stride + 1 : 0;
-    w.extra = -1;
-    return w;
-}
-// The same full rounds, but the last, partial round is dealt so that every CU gets the same number of TILES (+-1): first
-// whole pairs (q2 per CU, same slots and seams as a full round), then what is left one tile per CU -- CUs pb and pb + 1
-// (neighbours on one XCD under perm) take the two 64-byte halves of each output line, so the seams still meet in one L2.
-// 3,326 tiles: 13 per CU on 254 CUs, 12 on two -- 26 items per CU everywhere instead of 28 on one half of the chip.
-__host__ __device__ __forceinline__ ItemWalk item_walk_balanced(int slot, int slots, int b, int grid, int tiles) {
-    if (slots & 1) return item_walk_round_robin(slot, slots, b, grid, tiles);
-    const int pb = (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b;
-    const int per_round = slots * grid;
-    const int full = tiles / per_round;
-    const int rem = tiles - full * per_round;
-    const int q2 = (rem / grid) >> 1;            // whole pairs per CU in the partial round
-    ItemWalk w;
-    w.first = 2 * ((slot >> 1) * grid + pb) + (slot & 1);
-    w.stride = per_round;
-    w.n_regular = full + ((slot >> 1) < q2 ? 1 : 0);
-    const int k = slot - 2 * q2;                 // the slots behind the pairs take the single tiles
-    const int t = full * per_round + 2 * q2 * grid + k * grid + pb;
-    w.extra = (k == 0 || k == 1) && t < tiles ? t : -1;
-    return w;
-}
-__host__ __device__ __forceinline__ ItemWalk item_walk(int mode, int slot, int slots, int b, int grid, int tiles) {
-    return mode == 1 ? item_walk_balanced(slot, slots, b, grid, tiles) : item_walk_round_robin(slot, slots, b, grid, tiles);
-}
+// (Round 6, measured and rejected -- profiles/round6_probes/r6a, r6b: with 3,326 tiles on 256 CUs x 8 slots the second, partial
+// round gives the CUs of XCDs 0-3 three more tile pairs and those of XCDs 4-7 two -- 7 against 6 half-tile items on every SIMD,
+// and the stamped kernel shows XCDs 4-7 idle for the last 6 us of the launch.  Dealing the partial round evenly -- 13 whole
+// tiles on every CU of every XCD -- makes all eight XCDs exit together and the kernel no faster: 52.4 against 52.6 us back to
+// back, 56.3 against 54.4 behind a flush, the serial step 112.1 against 111.9, the in-flight step +0.3 ... +2.3 and the Q30
+// in-flight step +3: the duration is a chip-wide rate of the memory side, and in flight the XCDs that finish early take the other
+// batch's workgroups early.)
 
 // Pose part of the per-CU prologue: Mt[b] = f.R | t3d for the pass's MB columns (float64 rotation, network.py:266-297).
 // Needs >= 3*MB threads; ends with a workgroup barrier (so it also publishes whatever the caller staged before it).

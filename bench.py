@@ -459,7 +459,12 @@ def main():
     if inflight and args.q30_levels and not serial_plan.q30 and net._basis.q30_ws_bytes > 0:
         prev_arith, prev_lv = host.decode_arith(), host.q30_levels()
         host.set_decode_arith(host.DECODE_ARITH_Q30, args.q30_levels)
+        # An AUXILIARY leg: `value` (the f32 route) is already measured at this point and gated below.  Whatever goes wrong
+        # here -- the second 154 MB image, the extra plans, a mismatch against the Q30 oracle -- is reported inside
+        # q30_inflight (error / parity.ok = false, no figure quoted) and never takes the line down.
         try:
+            if os.environ.get("FR_BENCH_Q30_FAULT"):   # (tests/test_bench_gpu.py: the leg's failure path)
+                raise RuntimeError("FR_BENCH_Q30_FAULT is set: the Q30 leg fails on purpose")
             qplan = pipe.BatchesInFlight(net, B, H, W, slots=max(1, args.in_flight))
             for sl, pn in zip(qplan.slots, slot_params):
                 sl.params.copy_(torch.as_tensor(pn, device=dev))
@@ -482,19 +487,26 @@ def main():
                         "decode_inkernel_rotation_max_ulp": max(q["decode_inkernel_rotation"]["max_ulp"] for q in per),
                         "oracle": "oracle.decode_3dmm(q30=%d) -- the Q30 specification with %d levels, bit for bit -- and the oracle "
                                   "rasteriser on the plan's own vertices" % (args.q30_levels, args.q30_levels)}
-                all_q = dist_u.sum_over_ranks(0.0 if qpar["ok"] else 1.0, device=dev) == 0.0
-                if not all_q:
-                    print("bench.py: Q30 PARITY GATE FAILED on rank %d: %s" % (rank, json.dumps(qpar)), file=sys.stderr)
-                    dist_u.barrier()
-                    dist_u.finalize()
-                    sys.exit(3)
+                if not qpar["ok"]:
+                    print("bench.py: Q30 parity gate FAILED on rank %d (the Q30 figures are withheld; `value` is unaffected): %s"
+                          % (rank, json.dumps(qpar)), file=sys.stderr)
             q30_leg = {"levels": args.q30_levels, "elapsed": qelapsed, "blocks": qblocks, "serial_elapsed": qs_elapsed, "parity": qpar,
                        "serial_kernels_ms": {"decode (q_stage_kernel + decode_q_ring_kernel)": sum(e[0].elapsed_time(e[1]) for e in qs_ev) / len(qs_ev),
                                              "raster_emit": sum(e[1].elapsed_time(e[2]) for e in qs_ev) / len(qs_ev),
                                              "resolve_write": sum(e[2].elapsed_time(e[3]) for e in qs_ev) / len(qs_ev)}}
             del qplan, qserial
+        except Exception as e:  # noqa: BLE001
+            if world > 1:   # (the leg is full of collectives: a rank that leaves it alone would hang the others -- better to die)
+                raise
+            import traceback
+            traceback.print_exc()
+            q30_leg = {"levels": args.q30_levels, "error": "%s: %s" % (type(e).__name__, e)}
         finally:
             host.set_decode_arith(prev_arith, prev_lv)
+        # (a gate that failed on ONE rank is a failed gate for the line: the ranks agree before anything is reported)
+        q30_bad = q30_leg.get("parity") is not None and not q30_leg["parity"]["ok"]
+        if "error" not in q30_leg and dist_u.sum_over_ranks(1.0 if q30_bad else 0.0, device=dev) > 0 and not q30_bad:
+            q30_leg["parity"] = dict(q30_leg["parity"] or {}, ok=False, failed_on="another rank")
 
     # the operator-surface route (allocations + pack_tri every call): same K / W / R, reported beside `value`
     ops_elapsed = ops_same = None
@@ -625,10 +637,14 @@ def main():
         emit_bytes = (4.0 * 3 * N + (4.0 * 3 * T + 4.0 * 3 * N) / B) * B
         resolve_bytes = 4.0 * H * W * 8 * B
         q30 = serial_plan.q30   # FR_DECODE_ARITH=q30 (opt-in, frozen experiment; the default is the f32 chain)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except (OSError, ValueError):
+            pmc = {}
         ev_note = ("HIP events on the launch stream around each launch of every %dth step of the timed blocks (the step then goes "
                    "out launch by launch: separate C calls + event bubbles): an UPPER bound of the kernel's duration in the "
                    "un-bracketed steps; the rocprofv3 average of the same kernel is `rocprofv3_avg_ms` "
-                   "(profiles/round4_kernel_stats.csv, a PROFILED run: slower clock)" % EV_EVERY)
+                   "(%s, a PROFILED run: slower clock)" % (EV_EVERY, pmc.get("kernel_stats_csv", "profiles/, the round's kernel_stats.csv")))
         if in_region is not None:
             ev_note += ("; taken in the SERIAL leg of this process (one plan, one stream, one batch in flight; its throughput is "
                         "`serial_plan_faces_per_s`): with two batches in flight a kernel's bracketed duration measures how the two "
@@ -648,10 +664,10 @@ def main():
                            "algorithmic_bytes_per_launch": ab["decode"] * B,
                            "which_side_binds": "THIS KERNEL ALONE: priced against the fp32 MFMA peak because the flops put it at the "
                                "ridge (29.6 us of MFMA vs 23.4 us of HBM at the spec peaks), but the ablation says its MEMORY side "
-                               "binds: with its MFMAs removed it takes 50-53 us, with its stores removed 47 us, MFMA-only 36 us at "
-                               "the clock it holds (DESIGN.md 4.1, profiles/round3_decode_breakdown.json): read `frac` as "
-                               "matrix-pipe utilisation and hbm_frac_of_8TBs as the HBM roofline fraction.  THE STEP is another "
-                               "question, answered under `vector_pipe.is`"}
+                               "binds: with its MFMAs removed it takes 47-50 us, with its stores removed 44-47 us, MFMA-only 36 us at "
+                               "the clock it holds (DESIGN.md 4.1, profiles/round5_decode_breakdown.json): read `frac` as "
+                               "matrix-pipe utilisation and hbm_frac_of_8TBs as the HBM roofline fraction.  THE STEP is priced "
+                               "under `roofline.step`"}
         kernels = {"decode": roof_decode}
         if piped:
             render_bytes = emit_bytes + resolve_bytes
@@ -669,44 +685,17 @@ def main():
             kernels["resolve_write"] = {"bound": "hbm", "kernel": "resolve_write_kernel<256> (fr_decode_render_forward, phase 2)",
                                         "achieved": resolve_bytes / (resolve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "traffic": None, "avg_ms": resolve_ms, "algorithmic_bytes_per_launch": resolve_bytes}
-        vector_pipe = None
         # HBM traffic per launch + the rocprofv3 kernel averages, from the committed profile passes of this same command
         # (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc passes; ONE stated correction for all
         # kernels -- see its `correction` field -- so the figures of one line are comparable)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("batch") == B and (H, W) == (200, 200) and not q30:
-                pk = pmc.get("kernels")
-                for name, r in kernels.items():
-                    rec = pk.get(name) if isinstance(pk, dict) else None
-                    if rec:
-                        r["traffic"] = rec.get("traffic_bytes_per_launch")
-                        r["traffic_source"] = "profiles/pmc_traffic.json (%s)" % pmc.get("correction", "")
-                        if rec.get("rocprofv3_avg_ms") is not None:
-                            r["rocprofv3_avg_ms"] = rec["rocprofv3_avg_ms"]
-                vp = pmc.get("vector_pipe")
-                if isinstance(vp, dict):   # what the step asks of the vector ALUs (f32 MFMA included: it runs there)
-                    ghz = clocks["after_timed_blocks"][0]
-                    us_held = vp["step_cycles_per_simd"] / (ghz * 1e3)
-                    vector_pipe = {"cycles_per_simd_per_step": vp["step_cycles_per_simd"], "clock_GHz_held": ghz,
-                                   "us_at_clock_held": us_held, "us_at_2.1GHz": vp["step_us_at_2.1GHz"],
-                                   "per_kernel_cycles_per_simd": {k: vp[k]["cycles_per_simd"] for k in ("decode", "raster_emit", "resolve_write")},
-                                   "frac_of_ms_per_step": us_held * 1e-3 / (1e3 * elapsed / K),
-                                   "is": "PMC instruction counts of the three kernels (profiles/pmc_traffic.json: 32 cycles per "
-                                         "v_mfma_f32_16x16x4_f32, 4 per other wave64 vector instruction, per SIMD) at the clock the "
-                                         "probe of THIS run read (clock_GHz_held), against the measured step: the share of the step "
-                                         "the vector pipe alone accounts for.  Round 4 read this pipe as what the step is closest to "
-                                         "(the f32-input MFMA and every other vector instruction of a SIMD take turns: r4t).  Round 5 "
-                                         "tested that reading and it does NOT hold for the step: a decode with a third of the f32 "
-                                         "kernel's vector-pipe time (Q30, ten int8 digit products; `q30_inflight`) moves the in-flight "
-                                         "step by what its own DURATION changed (0.5-8 us depending on the box), not by the 17 us of "
-                                         "pipe time it frees, and a decode slimmed to co-reside "
-                                         "with the other batch's emit workgroups makes it 9 us longer (profiles/round5_probes/r5b).  "
-                                         "What binds the in-flight step is that each kernel fills every CU's registers / wave slots by "
-                                         "itself -- the two batches alternate on a CU instead of sharing it -- and the ~385 MB a step "
-                                         "moves; the pipe's share is an account, not the bound"}
-        except (OSError, ValueError, KeyError):
-            pass
+        if pmc.get("batch") == B and (H, W) == (200, 200) and not q30 and isinstance(pmc.get("kernels"), dict):
+            for name, r in kernels.items():
+                rec = pmc["kernels"].get(name)
+                if rec:
+                    r["traffic"] = rec.get("traffic_bytes_per_launch")
+                    r["traffic_source"] = "%s (%s)" % (pmc.get("source_file", "profiles/pmc_traffic.json"), pmc.get("correction", ""))
+                    if rec.get("rocprofv3_avg_ms") is not None:
+                        r["rocprofv3_avg_ms"] = rec["rocprofv3_avg_ms"]
         for name, r in kernels.items():
             r["frac"] = r["achieved"] / r["peak"]
             r["avg_ms_is"] = ev_note
@@ -770,11 +759,6 @@ def main():
                                     "triangle list every call (fr_render_depth_forward) pays one more 5 us kernel per step"},
             "roofline": dominant,
             "kernels": kernels,
-            "pipeline_hbm": {"bytes_per_face": ab["pipeline"],
-                             "achieved_GBs": ab["pipeline"] * value / world / 1e9,
-                             "frac_of_8TBs": ab["pipeline"] * value / world / 1e9 / HBM_PEAK_GBS,
-                             "frac_of_measured_copy_6.29TBs": ab["pipeline"] * value / world / 1e9 / HBM_COPY_GBS},
-            "vector_pipe": vector_pipe,
             "parity": parity,
             "dist": dict(dist_info, per_rank_ms_per_step=per_rank_ms, launcher_world_size=world),
         }
@@ -790,7 +774,13 @@ def main():
             out["serial_plan"] = {"ms_per_step": 1e3 * serial_elapsed / K, "timed_route_vs_serial": serial_elapsed / elapsed,
                                   "route": "DecodeRenderPlan.step(): decode -> emit -> resolve, three launches, same process, "
                                            "same K / W / R (median block)"}
-        if q30_leg is not None:
+        need = 0.4 * HBM_PEAK_GBS * 1e9 / ab["pipeline"]   # north_star: ">= 40 % of the HBM roofline", per GPU
+        q30_ok = q30_leg is not None and "error" not in q30_leg and (q30_leg["parity"] is None or q30_leg["parity"]["ok"])
+        if q30_leg is not None and not q30_ok:
+            # the leg failed or its gate did: no Q30 figure is quoted anywhere in the line
+            out["q30_inflight"] = {"levels": q30_leg["levels"], "error": q30_leg.get("error", "Q30 parity gate failed"),
+                                   "parity": q30_leg.get("parity")}
+        elif q30_leg is not None:
             qv = faces_per_step * K / q30_leg["elapsed"]
             out["q30_inflight_faces_per_s"] = qv
             out["q30_inflight"] = {
@@ -806,15 +796,44 @@ def main():
                 "why_not_value": "the two arithmetics are two written definitions of the same blend, each held to its own CPU "
                                  "restatement bit for bit; `value` stays on the f32 chain (the reference's arithmetic type, the "
                                  "figure rounds 1-4 reported).  Same route, same K / W / R, same slots' parameters"}
-        # north_star: ">= 40 % of the HBM roofline" = algorithmic bytes per face x faces/s >= 0.4 x 8 TB/s, per GPU
-        need = 0.4 * HBM_PEAK_GBS * 1e9 / ab["pipeline"]
-        out["north_star_40pct_of_8TBs"] = {
-            "needs_faces_per_s_per_gpu": need, "needs_ms_per_step": 1e3 * B / need,
-            "value (f32 chain, %s)" % out["value_route"]: bool(value / world >= need),
-            "value_one_batch_at_a_time (f32 chain, serial plan)": (bool(faces_per_step * K / serial_elapsed / world >= need)
-                                                                   if serial_elapsed is not None else None),
-            "q30_inflight (Q30 decode, %s)" % out["value_route"]: (bool(out["q30_inflight_faces_per_s"] / world >= need)
-                                                                    if q30_leg is not None else None)}
+        # ---- everything a reader needs to recompute the line's fractions, INSIDE `roofline` (the object the driver's record keeps):
+        #      the dominant kernel's own fields (above), the other kernels in short, the whole step, the Q30 step, the clock ----
+        per_gpu = value / world
+        serial_v = (faces_per_step * K / serial_elapsed) if serial_elapsed is not None else (value if not (inflight or piped) else None)
+        step = {"what": "the WHOLE step (decode -> emit -> resolve) against the HBM roofline: algorithmic bytes per face (SURVEY.md 8d: "
+                        "basis / B + params + 2 x vertices + (triangles + texture) / B + four planes) x faces/s per GPU / 8 TB/s",
+                "algorithmic_bytes_per_face": ab["pipeline"], "faces_per_step_per_gpu": B, "route": out["value_route"],
+                "batches_in_flight": out["config"]["batches_in_flight"],
+                "ms_per_step": 1e3 * elapsed / K, "faces_per_s_per_gpu": per_gpu,
+                "achieved_GBs": ab["pipeline"] * per_gpu / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                "frac_of_8TBs": ab["pipeline"] * per_gpu / 1e9 / HBM_PEAK_GBS,
+                "frac_of_measured_copy_6.29TBs": ab["pipeline"] * per_gpu / 1e9 / HBM_COPY_GBS,
+                "one_batch_at_a_time": None if serial_v is None else {
+                    "faces_per_s_per_gpu": serial_v / world, "ms_per_step": 1e3 * B * world / serial_v,
+                    "frac_of_8TBs": ab["pipeline"] * serial_v / world / 1e9 / HBM_PEAK_GBS},
+                "north_star_40pct": {"needs_faces_per_s_per_gpu": need, "needs_ms_per_step": 1e3 * B / need,
+                                     "value_passes": bool(per_gpu >= need),
+                                     "one_batch_at_a_time_passes": None if serial_v is None else bool(serial_v / world >= need),
+                                     "q30_passes": bool(out["q30_inflight_faces_per_s"] / world >= need) if q30_ok else None}}
+        roof = dict(dominant)
+        roof["step"] = step
+        roof["q30"] = None if q30_leg is None else (
+            {"levels": q30_leg["levels"], "error": out["q30_inflight"]["error"], "parity_ok": False if q30_leg.get("parity") else None}
+            if not q30_ok else
+            {"levels": q30_leg["levels"], "faces_per_s_per_gpu": out["q30_inflight_faces_per_s"] / world,
+             "ms_per_step": out["q30_inflight"]["ms_per_step"], "frac_of_8TBs": out["q30_inflight"]["frac_of_8TBs"],
+             "parity_ok": None if q30_leg["parity"] is None else bool(q30_leg["parity"]["ok"]),
+             "faces_checked": None if q30_leg["parity"] is None else q30_leg["parity"]["faces_checked"],
+             "one_batch_at_a_time_ms_per_step": out["q30_inflight"]["serial_plan_ms_per_step"],
+             "one_batch_at_a_time_frac_of_8TBs": ab["pipeline"] * out["q30_inflight"]["serial_plan_faces_per_s"] / world / 1e9 / HBM_PEAK_GBS,
+             "is": "the same route with the Q30 decode (a second written definition of the blend, gated against ITS oracle): "
+                   "reported beside `value`, never as it"})
+        roof["clock_GHz_held"] = {k: v[0] for k, v in clocks.items()}
+        roof["kernels"] = {name: {k: r.get(k) for k in ("bound", "avg_ms", "achieved", "peak", "unit", "frac", "traffic",
+                                                           "algorithmic_bytes_per_launch", "algorithmic_flop_per_launch",
+                                                           "rocprofv3_avg_ms", "in_region_avg_ms") if r.get(k) is not None}
+                           for name, r in kernels.items() if name != "render_op"}
+        out["roofline"] = roof
         if rccl_st is not None:
             out["dist"]["rccl_selftest"] = rccl_st
         if allreduce is not None:
@@ -839,10 +858,11 @@ def main():
                                    "what": "hipGraph replays of the serial plan's three launches; R steps per graph = "
                                            "pipeline.GraphedSteps (R plans, one hipGraphLaunch per R batches): the ~9 us bubble "
                                            "between two replays (profiles/round4_probes/r4h) is paid once per R batches"}
-        if args.cpu_faces > 0 and world == 1:
+        if args.cpu_faces > 0:   # rank 0 only, at every N (the other ranks wait at the closing barrier)
             cb = cpu_baseline(assets, params_np, args.cpu_faces, H, W, synth)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu"] = {
+                "n_gpus": world,
                 "vs_cpu_baseline_value (decode + op functor, 1 thread)": value / cb["value"],
                 "vs_north_star_reference_cpu_zbuffer (render only, 1 thread; the GPU figure includes the decode)":
                     value / cb["north_star_reference_cpu_zbuffer"]["faces_per_s"]}

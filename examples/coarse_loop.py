@@ -109,30 +109,41 @@ def run_test_phase(args, dev, rank, world, local, dist_u):
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
     images = [torch.rand((B, S, S, 1), generator=g).to(dev) for _ in range(4)]   # the "test generator": four resident batches
 
-    def consume(slot):
+    dumped = []   # --dump-batches: what every timed batch left in its slot (copied out by the CONSUMER, on the current stream)
+
+    def consume(slot, keep=False):
         """trainval.py:196: depth_images = pred_depth * 255.0, one image per face (written to disk there)."""
         slot.make_current_stream_wait()
+        if keep:
+            dumped.append([t.clone() for t in (slot.params, slot.vertex_proj.contiguous()) + tuple(slot.outputs())])
         return (slot.depth.clamp_min(1e-6) * 255.0).sum(dim=(1, 2, 3))
 
-    def loop(n):
+    def loop(n, keep=False):
         sums, pending = [], None
         with torch.no_grad():
             for k in range(n):
                 params = coarse(images[k % len(images)])           # the dependent chain of THIS batch (current stream)
                 slot = flights.submit(params)                       # its depth rendering: the slot's stream, nothing waits for it yet
                 if pending is not None:
-                    sums.append(consume(pending))                   # batch k-1's planes, behind ITS slot
+                    sums.append(consume(pending, keep))             # batch k-1's planes, behind ITS slot
                 pending = slot
-            sums.append(consume(pending))
+            sums.append(consume(pending, keep))
         return sums
 
     loop(max(args.warmup, 1))
     torch.cuda.synchronize(dev)
     dist_u.barrier()
     t0 = time.perf_counter()
-    sums = loop(args.steps)
+    sums = loop(args.steps, keep=bool(args.dump_batches))
     torch.cuda.synchronize(dev)
     dt = dist_u.max_over_ranks(time.perf_counter() - t0, device=dev)
+    if args.dump_batches and rank == 0:
+        # every timed batch's predicted parameters, vertices and four planes as the consumer saw them: tests/test_programs_gpu.py
+        # holds them to the CPU oracle (this program never loads it)
+        import numpy as np
+        names = ("params", "vertex_proj", "depth", "texture_image", "normal", "tri_ind")
+        np.savez(args.dump_batches, steps=len(dumped), mu=A["mu"], pc_shape=A["pc_shape"], pc_exp=A["pc_exp"], tri=A["tri"], vertex=A["vertex"],
+                 im_size=S, **{"%s_%d" % (n, k): t.cpu().numpy() for k, rec in enumerate(dumped) for n, t in zip(names, rec)})
     # the same batches one at a time through the plain surface: the in-flight loop must reproduce them bit for bit
     with torch.no_grad():
         ref = []
@@ -190,6 +201,9 @@ def main():
     ap.add_argument("--fine", action="store_true")
     ap.add_argument("--gather-sfs", action="store_true", help="whole-batch SfS lighting estimate across ranks")
     ap.add_argument("--small", action="store_true", help="tiny synthetic assets (smoke runs)")
+    ap.add_argument("--dump-batches", default=None, metavar="FILE.npz",
+                    help="--phase test: save every timed batch's parameters, vertices and planes (as its consumer saw them) for an "
+                         "external checker")
     ap.add_argument("--phase", choices=("train", "test"), default="train",
                     help="trainval.py's phase switch (:223-225).  test = the forward-only evaluation loop over independent batches "
                          "with the depth rendering in flight (run_test_phase); train = everything else this script does")

@@ -45,7 +45,8 @@ const char* fr_strerror(int code);
  * that gives it its initial value -- read ONCE per process, at the first use of any knob; the launch path never calls
  * getenv -- and can be changed afterwards only through fr_set_option:
  *   FR_DECODE_IMPL (0 | 1 = "loop": generic decode kernel)   FR_DECODE_WIDE (1 | 0)   FR_DECODE_NBW (0 = auto | 1 | 4)
- *   FR_DECODE_WAVES (16 | 8)   FR_DECODE_NT (1 | 0: default cache policy for the basis stream)
+ *   FR_DECODE_WAVES (16 | 8)   FR_DECODE_NT (-1 = by batch: non-temporal basis stream for passes of 64 faces, default cache
+ *   policy below -- default | 1 = always non-temporal | 0 = always the default cache policy)
  *   FR_RESOLVE_OPT (2 = default: wave-local front for 256-thread bins | 1 = block-wide list, single-trip bins keep their
  *   records in registers | 0 = two-pass resolver)   FR_EMIT_FILTER (bits 0-1, default 3)   FR_RENDER_IMPL (0 | 1 = "scan": strip-scan fallback)
  *   FR_RESOLVE_BLOCK (0 = auto | 256 | 512 | 1024)   FR_RENDER_ROWS (0 = auto | rows per screen strip)

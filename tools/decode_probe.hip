@@ -263,13 +263,12 @@ static void stamped(const Ctx& c, bool flush, const char* name, unsigned long lo
 
 int main(int argc, char** argv) {
     using namespace fr;
-    // decode_probe [B] [N] [pitched rows 0|1] [quick 0|1|2 (2 = tile-walk / ring-depth / priority A/B + stamps by XCD of both walks)] [wave priorities 0|1] [pitch/prio A/B 0|1] [walk 0|1]
+    // decode_probe [B] [N] [pitched rows 0|1] [quick 0|1|2 (2 = ring-depth / priority A/B + stamps by XCD)] [wave priorities 0|1] [pitch/prio A/B 0|1]
     const int B = argc > 1 ? atoi(argv[1]) : 64, N = argc > 2 ? atoi(argv[2]) : 53215, ns = 199, ne = 29;
     const int pitched = argc > 3 ? atoi(argv[3]) : 1;
     const bool quick = argc > 4 && atoi(argv[4]) == 1;
     const bool saw_ab = argc > 4 && atoi(argv[4]) == 2;
     g_prio = argc > 5 ? atoi(argv[5]) : 1;
-    const int walk_arg = argc > 7 ? atoi(argv[7]) : 1;
     const size_t pb = fr_packed_basis_bytes(N, ns, ne);
     void *packed, *params, *out, *flush;
     unsigned long long* dstamps;
@@ -293,7 +292,7 @@ int main(int argc, char** argv) {
     c.a.mu_p = (const float*)(c.a.A + tiles * G * 3 * 64);
     c.a.R_override = nullptr;
     c.a.out = (float*)out;
-    c.a.B = B; c.a.N = N; c.a.ns = ns; c.a.ne = ne; c.a.b0 = 0; c.a.halves = B > 32 ? 2 : 1; c.a.walk = walk_arg; c.a.im_size = 200.f; c.a.pitch = pitched ? (N + 31) & ~31 : N;
+    c.a.B = B; c.a.N = N; c.a.ns = ns; c.a.ne = ne; c.a.b0 = 0; c.a.halves = B > 32 ? 2 : 1; c.a.im_size = 200.f; c.a.pitch = pitched ? (N + 31) & ~31 : N;
     c.lds = G * KGROUP * 16 * sizeof(float4) + 64 * 12 * sizeof(float) + 64 * 3 * 2 * sizeof(double);
     c.grid = std::min(fr_device_cu_count(), (int)((tiles + 16 / c.a.halves - 1) / (16 / c.a.halves)));
     c.st = 0;
@@ -321,16 +320,16 @@ int main(int argc, char** argv) {
     printf("{\"device\": \"%s\", \"cus\": %d, \"B\": %d, \"N\": %d, \"row_pitch\": %d, \"wave_priorities\": %d, \"items\": %zu, \"mfma_per_item\": 348,\n", prop.gcnArchName, c.grid, B, N, c.a.pitch, g_prio, tiles * 2);
     printf(" \"mfma_floor_us_at_2.4GHz\": {\"average_6.5_items_per_simd\": %.2f, \"worst_simd_7_items\": %.2f},\n",
            tiles * 2 * 348.0 * 32.0 / 1024.0 / 2.4e3, 7 * 348.0 * 32.0 / 2.4e3);
-    if (saw_ab) {   // interleaved A/B in one process: tile walk x basis policy, ring depth, wave priorities; then the stamps of both walks
-        struct V { const char* name; int walk, ring, prio; };
-        const V vs[] = {{"walk=0 ring=8 prio=1 (round 5)", 0, 8, 1}, {"walk=1 ring=8 prio=1", 1, 8, 1}, {"walk=1 ring=6 prio=1", 1, 6, 1},
-                        {"walk=1 ring=4 prio=1", 1, 4, 1}, {"walk=1 ring=8 prio=0", 1, 8, 0}};
+    if (saw_ab) {   // interleaved A/B in one process: ring depth and wave priorities; then the stamped kernel by XCD
+        // (round 6, r6a / r6b: the store-aware waits and the balanced tile walk were A/B'd through this mode; both lost and left the tree)
+        struct V { const char* name; int ring, prio; };
+        const V vs[] = {{"ring=8 prio=1 (product)", 8, 1}, {"ring=6 prio=1", 6, 1}, {"ring=4 prio=1", 4, 1}, {"ring=8 prio=0", 8, 0}};
         const int nv = sizeof(vs) / sizeof(vs[0]);
         printf(" \"ab_us\": {\n");
         std::vector<double> r[8][4];
         for (int round = 0; round < 5; round++)
             for (int v = 0; v < nv; v++) {
-                c.a.walk = vs[v].walk; g_ring = vs[v].ring; g_prio = vs[v].prio;
+                g_ring = vs[v].ring; g_prio = vs[v].prio;
                 r[v][0].push_back(time_us<true, AblateProbe<0>>(c, true, 9));
                 r[v][1].push_back(time_b2b_us<true, AblateProbe<0>>(c, 200));
                 r[v][2].push_back(time_us<false, AblateProbe<0>>(c, true, 9));
@@ -342,11 +341,8 @@ int main(int argc, char** argv) {
                    med(r[v][0]), vmin(r[v][0]), vmax(r[v][0]), med(r[v][1]), vmin(r[v][1]), med(r[v][2]), vmin(r[v][2]), med(r[v][3]), vmin(r[v][3]), v == nv - 1 ? "" : ",");
         printf(" },\n \"stamps\": [\n");
         g_ring = 8; g_prio = 1;
-        c.a.walk = 0;
-        stamped<true, 0>(c, true, "round-robin walk (round 5), nt basis from HBM", dstamps, false);
-        c.a.walk = 1;
-        stamped<true, 0>(c, true, "balanced walk, nt basis from HBM", dstamps, false);
-        stamped<false, 0>(c, false, "balanced walk, default-policy basis back to back (Infinity-Cache resident)", dstamps, true);
+        stamped<true, 0>(c, true, "product configuration (nt basis), basis from HBM", dstamps, false);
+        stamped<false, 0>(c, false, "default-policy basis back to back (Infinity-Cache resident)", dstamps, true);
         printf(" ]}\n");
         return 0;
     }
