@@ -160,11 +160,6 @@ def _bind(L):
     L.fr_decode_render_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _vp,
                                            ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, _i]
     L.fr_decode_render_forward.restype = _i
-    L.fr_decode_render_pipelined_supported.argtypes = [_i] * 5
-    L.fr_decode_render_pipelined_supported.restype = _i
-    L.fr_decode_render_pipelined.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _vp, _vp,
-                                             ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, _i]
-    L.fr_decode_render_pipelined.restype = _i
     L.fr_set_option.argtypes = [ctypes.c_char_p, _i]
     L.fr_set_option.restype = _i
     L.fr_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
@@ -201,7 +196,6 @@ EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_r
            "fr_decode_q30_image_bytes", "fr_decode_q30_pack", "fr_decode_q30_workspace_bytes", "fr_decode_3dmm_q30",
            "fr_decode_3dmm_q30_lv", "fr_decode_render_forward_q30",
            "fr_decode_render_vertex_pitch", "fr_decode_render_vertex_bytes", "fr_decode_render_forward",
-           "fr_decode_render_pipelined_supported", "fr_decode_render_pipelined",
            "fr_decode_backward_basis_bytes", "fr_decode_backward_pack_basis", "fr_decode_3dmm_backward_packed",
            "fr_debug_clock_probe", "fr_rendering_layer_forward_phases", "fr_decode_3dmm_backward_packed_mu"]
 

@@ -17,7 +17,6 @@ const OptDesc kOpts[fr::OPT_COUNT] = {
     {"FR_DECODE_WAVES", 16, nullptr}, {"FR_DECODE_NT", -1, nullptr}, {"FR_RESOLVE_OPT", 2, nullptr},
     {"FR_EMIT_FILTER", 3, nullptr}, {"FR_RENDER_IMPL", 0, "scan"}, {"FR_RESOLVE_BLOCK", 0, nullptr},
     {"FR_RENDER_ROWS", 0, nullptr}, {"FR_DECODE_STORE", 0, nullptr},
-    {"FR_FUSED_ORDER", 0, nullptr}, {"FR_FUSED_ALONE", 0, nullptr},
     {"FR_BWD_CHUNKS", 256, nullptr}, {"FR_BWD_CB", 0, nullptr}, {"FR_EMIT_ORDER", -1, nullptr},
     {"FR_Q30_SCHED", 0, nullptr},
 };
@@ -212,7 +211,7 @@ int fr_decode_render_forward(const float* params, const void* packed_basis, cons
                              int tex_batch, float im_size, float* vertex_handoff, size_t vertex_bytes, float* depth,
                              float* tex_img, float* normal, float* tri_ind, void* workspace, size_t ws_bytes,
                              void* hip_stream, int phases) {
-    if (phases < 1 || phases > 15) return FR_ERR_INVALID_ARG;
+    if ((phases & 15) < 1 || (phases & ~0xFF0F)) return FR_ERR_INVALID_ARG;   // bits 0-3: phases; bits 8-15: strip-height hint
     if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
     if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
     if (B == 0) return FR_OK;
@@ -232,44 +231,7 @@ int fr_decode_render_forward(const float* params, const void* packed_basis, cons
     if (ntri >= (1 << 24)) return FR_ERR_UNSUPPORTED;
     if (ws_bytes < fr_render_depth_workspace_bytes(B, N, ntri, H, W)) return FR_ERR_WORKSPACE;
     return fr_launch_render_forward_phases(vertex_handoff, tri, texture, B, N, ntri, H, W, tex_batch, depth, tex_img, normal,
-                                           tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream, phases & 7, pitch);
-}
-
-// ---- pipelined step: decode + [emit of this batch || resolve of the previous batch] ------------------------------------------
-int fr_decode_render_pipelined_supported(int B, int N, int ntri, int H, int W) {
-    if (B <= 0 || N <= 0 || ntri <= 0 || ntri >= (1 << 24)) return 0;
-    return fr_render_pipelined_supported_impl(B, ntri, H, W);
-}
-
-int fr_decode_render_pipelined(const float* params, const void* packed_basis, const float* R_override, const float* tri,
-                               const float* texture, int B, int N, int n_shape, int n_exp, int ntri, int H, int W,
-                               int tex_batch, float im_size, float* vertex_new, const float* vertex_prev, size_t vertex_bytes,
-                               float* depth, float* tex_img, float* normal, float* tri_ind, void* workspace_new,
-                               void* workspace_prev, size_t ws_bytes, void* hip_stream, int phases) {
-    if (phases < 1 || phases > 15) return FR_ERR_INVALID_ARG;
-    if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
-    if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
-    if (!fr_decode_render_pipelined_supported(B, N, ntri, H, W)) return FR_ERR_UNSUPPORTED;
-    const int pitch = fr_decode_render_vertex_pitch(N);
-    if (vertex_bytes < fr_decode_render_vertex_bytes(B, N)) return FR_ERR_WORKSPACE;
-    if ((phases & 9) && (!vertex_new || ((uintptr_t)vertex_new & 127))) return FR_ERR_WORKSPACE;
-    if ((phases & 2) && (!vertex_prev || ((uintptr_t)vertex_prev & 127))) return FR_ERR_WORKSPACE;
-    if (ws_bytes < fr_render_depth_workspace_bytes(B, N, ntri, H, W)) return FR_ERR_WORKSPACE;
-    if ((phases & 5) && (!workspace_new || ((uintptr_t)workspace_new & 15))) return FR_ERR_WORKSPACE;
-    if ((phases & 2) && (!workspace_prev || ((uintptr_t)workspace_prev & 15))) return FR_ERR_WORKSPACE;
-    // two batches in flight need a workspace and a vertex buffer each
-    if ((phases & 2) && (phases & 9) && (workspace_new == workspace_prev || vertex_new == vertex_prev)) return FR_ERR_INVALID_ARG;
-    if (phases & 8) {
-        if (!params || !packed_basis || ((uintptr_t)packed_basis & 15) != 0) return FR_ERR_INVALID_ARG;
-        const int rc = fr_launch_decode(params, packed_basis, R_override, B, N, n_shape, n_exp, im_size, vertex_new, pitch,
-                                        (hipStream_t)hip_stream);
-        if (rc != FR_OK) return rc;
-    }
-    if (!(phases & 7)) return FR_OK;
-    if (!tri || !texture) return FR_ERR_INVALID_ARG;
-    if ((phases & 2) && (!depth || !tex_img || !normal || !tri_ind)) return FR_ERR_INVALID_ARG;
-    return fr_launch_render_pipelined(vertex_new, vertex_prev, pitch, tri, texture, B, N, ntri, H, W, tex_batch, depth, tex_img, normal,
-                                      tri_ind, workspace_new, workspace_prev, ws_bytes, (hipStream_t)hip_stream, phases & 7);
+                                           tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream, phases & 7, pitch, (phases >> 8) & 0xFF);
 }
 
 // ---- opt-in Q30 arithmetic: its own image, its own entry point, caller-owned staging workspace ----------------------------
@@ -326,7 +288,7 @@ int fr_decode_render_forward_q30(const float* params, const void* qimage, const 
                                  int tex_batch, float im_size, int levels, float* vertex_handoff, size_t vertex_bytes,
                                  float* depth, float* tex_img, float* normal, float* tri_ind, void* workspace, size_t ws_bytes,
                                  void* q_workspace, size_t q_ws_bytes, void* hip_stream, int phases) {
-    if (phases < 1 || phases > 15) return FR_ERR_INVALID_ARG;
+    if ((phases & 15) < 1 || (phases & ~0xFF0F)) return FR_ERR_INVALID_ARG;   // bits 0-3: phases; bits 8-15: strip-height hint
     if (B < 0 || N < 0 || n_shape < 0 || n_exp < 0 || ntri < 0 || H < 0 || W < 0) return FR_ERR_INVALID_ARG;
     if (tex_batch != 1 && tex_batch != B) return FR_ERR_INVALID_ARG;
     if (!fr_decode_q_levels_ok(levels)) return FR_ERR_INVALID_ARG;
@@ -345,7 +307,7 @@ int fr_decode_render_forward_q30(const float* params, const void* qimage, const 
     if (ntri >= (1 << 24)) return FR_ERR_UNSUPPORTED;
     if (ws_bytes < fr_render_depth_workspace_bytes(B, N, ntri, H, W)) return FR_ERR_WORKSPACE;
     return fr_launch_render_forward_phases(vertex_handoff, tri, texture, B, N, ntri, H, W, tex_batch, depth, tex_img, normal,
-                                           tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream, phases & 7, pitch);
+                                           tri_ind, workspace, ws_bytes, (hipStream_t)hip_stream, phases & 7, pitch, (phases >> 8) & 0xFF);
 }
 
 int fr_debug_clock_probe(unsigned long long* ticks, int blocks, int iters, void* hip_stream) {

@@ -112,8 +112,6 @@ enum Opt {
     OPT_RESOLVE_BLOCK,  // FR_RESOLVE_BLOCK  0 = auto, 256 / 512 / 1024 threads per resolver workgroup
     OPT_RENDER_ROWS,    // FR_RENDER_ROWS    0 = auto, > 0 = rows per screen strip
     OPT_DECODE_STORE,   // FR_DECODE_STORE   0 = default epilogue, 1 = transposed accumulators + one dword per lane (A/B knob)
-    OPT_FUSED_ORDER,    // FR_FUSED_ORDER    resolve blocks of the fused launch: 0 = spread evenly (default), 1 = first, 2 = last
-    OPT_FUSED_ALONE,    // FR_FUSED_ALONE    1 = a lone emit / resolve phase of the pipelined entry also runs through the fused kernel (probe)
     OPT_BWD_CHUNKS,     // FR_BWD_CHUNKS     row chunks (workgroups, partial slabs) of the packed decode-backward GEMM: 256 (default: one workgroup per CU), 1 .. 512
     OPT_BWD_CB,         // FR_BWD_CB         16-coefficient blocks per wave of the fused decode backward: 0 = by batch (default) | 2 | 4
     OPT_EMIT_ORDER,     // FR_EMIT_ORDER     lane order of a segment's triangles: -1 scored per segment (default), 0 identity, 1 even / odd passes
@@ -131,15 +129,10 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
 int fr_launch_render_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                                     int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
                                     float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases,
-                                    long long vpitch = 0);
+                                    long long vpitch = 0, int rows_hint = 0);
 int fr_launch_rendering_layer(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
                               int nver, int ntri, int H, int W, int tex_batch, float* net_in, float* depth_img,
                               float* depth, float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases = 7);
-int fr_render_pipelined_supported_impl(int B, int ntri, int H, int W);
-int fr_launch_render_pipelined(const float* vertex, const float* vertex_prev, long long vpitch, const float* tri,
-                               const float* texture, int B, int nver, int ntri, int H, int W, int tex_batch, float* depth,
-                               float* tex_img, float* normal, float* tri_ind, void* ws_new, void* ws_prev, size_t ws_bytes,
-                               hipStream_t stream, int phases);
 int fr_launch_render_backward(const float* depth_grad, const float* tri, const float* tri_ind, float* vertex_grad,
                               int B, int nver, int ntri, int H, int W, void* workspace, size_t ws_bytes,
                               hipStream_t stream);

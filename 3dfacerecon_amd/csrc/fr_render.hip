@@ -554,8 +554,7 @@ constexpr int EMIT_BLOCK = 256;
 constexpr int TPT = 2;                 // triangles per thread in phase A
 constexpr int EMIT_ACTIVE = SEG / TPT; // threads that own triangles in phase A (252 of 256)
 
-// LDS of one emit workgroup (20,424 B: eight of them share a CU's 160 KiB).  The stand-alone kernel declares it as static
-// __shared__ arrays; the fused emit || resolve launch carves it out of the block's one LDS array.
+// LDS of one emit workgroup (20,424 B: eight of them share a CU's 160 KiB), carved out of ONE array by offset.
 constexpr size_t EMIT_LDS_QA = 0;                                   // float4 qa[SEG]  phase A->B: x1 y1 x2 y2     B->C: the record
 constexpr size_t EMIT_LDS_QB = EMIT_LDS_QA + SEG * sizeof(float4);  // float4 qb[SEG]  phase A->B: x3 y3 z1 z2     B->C: its normal
 constexpr size_t EMIT_LDS_QD = EMIT_LDS_QB + SEG * sizeof(float4);  // uint2 qd[SEG]   .x: z3 (raw bits) in A->B, then bucket << 16 | pos
@@ -916,25 +915,12 @@ constexpr int SLOT_CAP = 3072;  // flattened record list of a bin kept in LDS (1
 constexpr size_t resolve_scratch_bytes(int block) {
     return 2 * (size_t)(block + 1) * 4 + (size_t)block * 2 + 64 * 4 + 16 + (size_t)SLOT_CAP * 4;
 }
-// LEAN form of the resolver (the resolve role of the fused emit || resolve launch): the whole bin lives in the LDS of ONE
-// emit workgroup (EMIT_LDS_BYTES) and the role stays inside the emit kernel's register budget (8 waves per SIMD), so that a
-// resolve block costs the emit blocks beside it no residency: keys of at most LEAN_KEYS_BYTES (8 rows of 200 pixels), the
-// wave-local front with a shorter slot list, fewer records parked in registers, four pixels per lane in the writer; the
-// general path's prefix arrays alias the slot list (it then finds its records by search).
-constexpr int LEAN_BLOCK = 256;
-constexpr size_t LEAN_KEYS_BYTES = 12800;
-constexpr int LEAN_SLOT_CAP = 1792;   // 448 per wave
-constexpr int LEAN_RF = 2;            // records (+ normals) a lane keeps in registers across the two passes
-static_assert(LEAN_KEYS_BYTES + 64 * 4 + (size_t)LEAN_SLOT_CAP * 4 <= EMIT_LDS_BYTES, "the lean resolver fits an emit workgroup's LDS");
-static_assert(2 * (size_t)(LEAN_BLOCK + 1) * 4 + (size_t)LEAN_BLOCK * 2 <= (size_t)LEAN_SLOT_CAP * 4, "prefix arrays alias the slot list");
-
 // The bin's records are spread over the face's segments (a few per segment).  Walking segments one after the other
 // would serialise ~4 dependent memory round trips per segment; instead the per-segment counts are prefix-summed in
 // LDS and the threads take records from the flattened list, so all record loads of a bin are in flight together.
-template <int BLOCK, bool FUSED, bool LEAN, class PR>
+template <int BLOCK, bool FUSED, class PR>
 __device__ __forceinline__ void resolve_body(const RenderArgs& a, const int bin, unsigned long long* keys, PR& pr) {
-    static_assert(!LEAN || BLOCK == LEAN_BLOCK, "the lean resolver is a 256-thread bin");
-    constexpr int CAP = LEAN ? LEAN_SLOT_CAP : SLOT_CAP;
+    constexpr int CAP = SLOT_CAP;
     const int tid = threadIdx.x;
     const int b = bin / a.strips;
     const int s = bin - b * a.strips;
@@ -943,21 +929,11 @@ __device__ __forceinline__ void resolve_body(const RenderArgs& a, const int bin,
     const int W = a.W;
     const int npix = (r1 - r0) * W;
     // scratch behind the keys of a full strip (the launcher sizes the dynamic LDS for it)
-    uint32_t *pref, *prefb, *wtot, *slotlist;
-    uint16_t* lo16;
-    if constexpr (LEAN) {
-        wtot = reinterpret_cast<uint32_t*>(keys + (size_t)a.rows * W);              // [64]
-        slotlist = wtot + 64;                                                       // [LEAN_SLOT_CAP]
-        pref = slotlist;                                                            // (general path only: aliases the slot list)
-        prefb = pref + BLOCK + 1;
-        lo16 = reinterpret_cast<uint16_t*>(prefb + BLOCK + 1);
-    } else {
-        pref = reinterpret_cast<uint32_t*>(keys + (size_t)a.rows * W);  // [BLOCK+1] small-record list offsets
-        prefb = pref + BLOCK + 1;                                         // [BLOCK+1] big-record list offsets
-        lo16 = reinterpret_cast<uint16_t*>(prefb + BLOCK + 1);           // [BLOCK]
-        wtot = reinterpret_cast<uint32_t*>(lo16 + BLOCK);                 // [64] (BLOCK even: 4-byte aligned)
-        slotlist = wtot + 64;                                             // [SLOT_CAP] record slot of list entry j
-    }
+    uint32_t* const pref = reinterpret_cast<uint32_t*>(keys + (size_t)a.rows * W);  // [BLOCK+1] small-record list offsets
+    uint32_t* const prefb = pref + BLOCK + 1;                                         // [BLOCK+1] big-record list offsets
+    uint16_t* const lo16 = reinterpret_cast<uint16_t*>(prefb + BLOCK + 1);           // [BLOCK]
+    uint32_t* const wtot = reinterpret_cast<uint32_t*>(lo16 + BLOCK);                 // [64] (BLOCK even: 4-byte aligned)
+    uint32_t* const slotlist = wtot + 64;                                             // [SLOT_CAP] record slot of list entry j
     const unsigned long long KBG = bg_key();
     for (int i = tid; i < npix; i += BLOCK) keys[i] = KBG;
     const float* __restrict__ vx = a.vertex + (size_t)b * 3 * a.vpitch;
@@ -984,8 +960,8 @@ __device__ __forceinline__ void resolve_body(const RenderArgs& a, const int bin,
     // fit its quarter of the list, or that saw a big record, says so and the whole bin takes the general path (the
     // speculative loads are dropped).
     if constexpr (BLOCK == 256) {
-        if (one_chunk && (LEAN || a.resolve_opt == 2)) {
-            constexpr int NW = BLOCK / 64, RF = LEAN ? LEAN_RF : 6, WCAP = CAP / NW;
+        if (one_chunk && a.resolve_opt == 2) {
+            constexpr int NW = BLOCK / 64, RF = 6, WCAP = CAP / NW;
             static_assert(64 * RF <= WCAP, "a wave's share of the slot list");
             const int lane = tid & 63, wave = tid >> 6;
             const int seg = lane * NW + wave;
@@ -1100,7 +1076,7 @@ __device__ __forceinline__ void resolve_body(const RenderArgs& a, const int bin,
                 if (FUSED)
                     write_strip_fused<BLOCK>(a, b, r0, npix, keys);
                 else
-                    write_strip<BLOCK, true, LEAN ? 4 : 8>(a, b, r0, npix, keys, vx, vy, vz);
+                    write_strip<BLOCK, true, 8>(a, b, r0, npix, keys, vx, vy, vz);
                 pr.finish(0);
                 return;
             }
@@ -1137,21 +1113,21 @@ __device__ __forceinline__ void resolve_body(const RenderArgs& a, const int bin,
                 // together -- ballot, readlane, strided fill -- instead of every segment's own thread: this phase 6.3 k ->
                 // 12.2 k cycles.  A strip's records are spread over MANY segments with a few entries each, not a few
                 // segments with many.)
-                if (!LEAN && tot_s <= (uint32_t)SLOT_CAP)
+                if (tot_s <= (uint32_t)SLOT_CAP)
                     for (uint32_t i = 0; i < hi - lo; i++) slotlist[ex_s + i] = (uint32_t)tid * SEG + lo + i;
                 __syncthreads();  // also orders the key initialisation before the first atomics
                 if (pass == 0 && c0 == 0) pr.template stamp<1>();   // scans + slot list done
             }
             // ---- this strip's small records (own bucket + the two boundary buckets) ----
             const uint32_t total = pref[BLOCK];
-            const bool listed = !LEAN && total <= (uint32_t)SLOT_CAP;
+            const bool listed = total <= (uint32_t)SLOT_CAP;
             // The usual bin -- every record fits one trip (six per lane), no big records -- keeps its records AND their
             // normals in registers across the barrier between the two passes: the second pass then issues no loads at all
             // (it used to re-read the records and only then gather the winners' normals: two dependent round trips of a
             // kernel whose front part is a chain of them).  Measured: 28.4 -> 27.5 us per launch with six records per
             // lane; four cover too few bins (no gain), eight cost the kernel its occupancy (28.8 us, and 31.6 without
             // the path) -- FR_RESOLVE_OPT=0 turns it off.
-            if (!LEAN && pass == 0 && one_chunk && a.resolve_opt && total <= (uint32_t)(BLOCK * 6) && prefb[BLOCK] == 0 && listed) {
+            if (pass == 0 && one_chunk && a.resolve_opt && total <= (uint32_t)(BLOCK * 6) && prefb[BLOCK] == 0 && listed) {
                 constexpr int RF = 6;
                 uint4 r[RF];
                 float4 nv[RF];
@@ -1281,7 +1257,7 @@ __device__ __forceinline__ void resolve_body(const RenderArgs& a, const int bin,
     if (FUSED)
         write_strip_fused<BLOCK>(a, b, r0, npix, keys);
     else
-        write_strip<BLOCK, true, LEAN ? 4 : 8>(a, b, r0, npix, keys, vx, vy, vz);
+        write_strip<BLOCK, true, 8>(a, b, r0, npix, keys, vx, vy, vz);
     pr.finish(0);
 }
 
@@ -1290,78 +1266,7 @@ __global__ __launch_bounds__(BLOCK) void resolve_write_kernel(RenderArgs a) {
     PR pr;
     pr.begin();
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-    resolve_body<BLOCK, FUSED, false, PR>(a, xcd_remap(blockIdx.x, gridDim.x), keys, pr);
-}
-
-// ---- fused launch: emit of one batch beside resolve of ANOTHER (the previous) batch ------------------------------------------
-// The emit kernel is bound by vector-instruction issue and leaves HBM idle; the resolver is bound by the store path (82 MB of
-// planes) behind a latency chain and leaves the vector units idle.  Run as two kernels on two streams they overlap (54.6 us
-// against 65.0 one after the other) but a cross-stream dependency per step costs more than that returns.  Here both are ROLES
-// of one launch, chosen by block index: every block depends only on EARLIER launches (the resolve role reads the records
-// the previous step's emit role wrote into the OTHER workspace), so there is no intra-launch dependency, no event, no fence.
-// Resolve blocks are spread evenly through the grid (one after every ~8 emit blocks): at any time a CU holds mostly emit
-// workgroups plus the odd resolver, whose memory waits the emit waves fill.  The resolve role is the LEAN resolver: it lives
-// in ONE emit workgroup's LDS and inside the emit kernel's register budget, so the emit role keeps its 8 workgroups per CU.
-struct FusedArgs {
-    RenderArgs e;   // emit role: the NEW batch (vertices in, records out)
-    RenderArgs r;   // resolve role: the PREVIOUS batch (records in, planes out)
-    int n_emit, n_res;
-    int order;      // A/B knob FR_FUSED_ORDER: 0 = resolve blocks spread evenly through the grid, 1 = all of them first, 2 = last
-    // the even spread (order 0): groups of one block of the rarer role + grp_q (the first grp_rem groups: grp_q + 1) of the other
-    int grp_q, grp_rem, minor_is_res;
-    uint32_t grp_magic_long, grp_magic_short;   // ceil(2^32 / (grp_q + 2)), ceil(2^32 / (grp_q + 1))
-};
-// (Each role reads ITS argument block straight from the kernarg segment, through a pointer the compiler cannot see through:
-// handed the by-value struct it loads both blocks at kernel entry, keeps them live through both roles and -- held to the
-// 80 SGPRs that eight workgroups per CU allow -- spills 74 of them to VGPR lanes, ~70 v_readlane inside the emit role's
-// 280 vector instructions per wave: the emit role alone ran 44.6 us where the emit kernel runs 36.7.)
-typedef const __attribute__((address_space(4))) FusedArgs* FusedArgsK;
-__global__ __launch_bounds__(LEAN_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_fused_kernel(FusedArgs f_unused) {
-    static_assert(LEAN_BLOCK == EMIT_BLOCK, "one block size for both roles");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[EMIT_LDS_BYTES];
-    NoEmitProbe pr;
-    (void)f_unused;
-    FusedArgsK f = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
-    const int n_emit = f->n_emit, n_res = f->n_res, order = f->order;
-    // -> is_res, idx: this block's role and its index within the role
-    bool is_res;
-    uint32_t idx;
-    if (order == 0 && f->grp_q > 0) {
-        // Even spread with no division: the grid is cut into n_minor GROUPS of one block of the rarer role followed by q or
-        // q + 1 blocks of the other (the first `rem` groups are the long ones); v / (q + 2) and v / (q + 1) through exact 2^32
-        // reciprocals from the host.  (A 64-bit v * n_res / total costs every wave ~200 instructions -- as many as the
-        // emit role's whole vector work: the emit role ALONE ran 41.5 us with it against the emit kernel's 36.8.)
-        const uint32_t v = (uint32_t)xcd_remap(blockIdx.x, gridDim.x);
-        const uint32_t q = (uint32_t)f->grp_q, rem = (uint32_t)f->grp_rem, nlong = rem * (q + 2);
-        uint32_t g, off;
-        if (v < nlong) {
-            g = __umulhi(v, f->grp_magic_long);
-            off = v - g * (q + 2);
-        } else {
-            const uint32_t v2 = v - nlong, g2 = __umulhi(v2, f->grp_magic_short);
-            g = rem + g2;
-            off = v2 - g2 * (q + 1);
-        }
-        const bool minor = off == 0;                       // the group's first block is the rarer role's
-        const uint32_t midx = g, Midx = v - (g + 1);       // index among the rarer role's blocks / among the others
-        is_res = minor == (f->minor_is_res != 0);
-        idx = minor ? midx : Midx;
-    } else if (order == 2) {     // emit blocks first (dispatch order), each role XCD-remapped within its own range
-        is_res = blockIdx.x >= (uint32_t)n_emit;
-        idx = is_res ? (uint32_t)xcd_remap(blockIdx.x - n_emit, n_res) : (uint32_t)xcd_remap(blockIdx.x, n_emit);
-    } else {                     // resolve blocks first (also: one of the roles has no blocks at all)
-        is_res = blockIdx.x < (uint32_t)n_res;
-        idx = is_res ? (uint32_t)xcd_remap(blockIdx.x, n_res) : (uint32_t)xcd_remap(blockIdx.x - n_res, n_emit);
-    }
-    if (is_res) {
-        const __attribute__((address_space(4))) RenderArgs* rp = &f->r;
-        asm volatile("" : "+s"(rp));
-        resolve_body<LEAN_BLOCK, false, true, NoEmitProbe>(*(const RenderArgs*)rp, (int)idx, reinterpret_cast<unsigned long long*>(lds), pr);
-    } else {
-        const __attribute__((address_space(4))) RenderArgs* ep = &f->e;
-        asm volatile("" : "+s"(ep));
-        emit_body<NoEmitProbe>(*(const RenderArgs*)ep, (int)idx, lds, pr);
-    }
+    resolve_body<BLOCK, FUSED, PR>(a, xcd_remap(blockIdx.x, gridDim.x), keys, pr);
 }
 
 // ---- backward: zeros + scatter-add of g/3 to the z row (render_depth_op.cc:345-363) -------------------------
@@ -1745,7 +1650,7 @@ static int launch_resolve(const fr::RenderArgs& a, long long nbins, size_t lds, 
 static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
                               int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
                               const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
-                              hipStream_t stream, int phases = 7, long long vpitch = 0);
+                              hipStream_t stream, int phases = 7, long long vpitch = 0, int rows_hint = 0);
 
 int fr_launch_render_forward(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                              int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
@@ -1758,9 +1663,9 @@ int fr_launch_render_forward(const float* vertex, const float* tri, const float*
 int fr_launch_render_forward_phases(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri,
                                     int H, int W, int tex_batch, float* depth, float* tex_img, float* normal,
                                     float* tri_ind, void* workspace, size_t ws_bytes, hipStream_t stream, int phases,
-                                    long long vpitch) {
+                                    long long vpitch, int rows_hint) {
     return launch_render_impl(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr,
-                              nullptr, nullptr, workspace, ws_bytes, stream, phases, vpitch);
+                              nullptr, nullptr, workspace, ws_bytes, stream, phases, vpitch, rows_hint);
 }
 
 int fr_launch_rendering_layer(const float* vertex, const float* tri, const float* texture, const float* im_gray, int B,
@@ -1816,7 +1721,7 @@ static int prepare_render(const float* vertex, const float* tri, const float* te
 static int launch_render_impl(const float* vertex, const float* tri, const float* texture, int B, int nver, int ntri, int H,
                               int W, int tex_batch, float* depth, float* tex_img, float* normal, float* tri_ind,
                               const float* im_gray, float* net_in, float* depth_img, void* workspace, size_t ws_bytes,
-                              hipStream_t stream, int phases, long long vpitch) {
+                              hipStream_t stream, int phases, long long vpitch, int rows_hint) {
     using namespace fr;
     const bool fused = net_in != nullptr;
     constexpr int BLOCK = 1024;
@@ -1824,8 +1729,13 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     RenderArgs a;
     RenderGeom g;
     bool binned = false;
+    // The caller's strip-height hint (fr_decode_render_forward, phase bits 8-15) is taken only where the binned rasteriser serves
+    // the resulting geometry; anything else keeps the library's own choice.  No workspace size depends on the strip height and
+    // no result bit does (tests hold every height to the oracle): the hint only changes how many resolver workgroups there are.
+    // (... and only where the library's own geometry is binned too: that is what the caller's workspace was sized for)
+    if (rows_hint > 0 && !(render_geom(B, ntri, H, W, rows_hint).binned_ok && render_geom(B, ntri, H, W).binned_ok)) rows_hint = 0;
     const int prc = prepare_render(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, im_gray,
-                                   net_in, depth_img, workspace, ws_bytes, vpitch, a, g, &binned);
+                                   net_in, depth_img, workspace, ws_bytes, vpitch, a, g, &binned, rows_hint > 0 ? rows_hint : -1);
     if (prc != FR_OK) return prc;
     const long long nbins = (long long)B * g.strips;
     if (!binned) {
@@ -1854,96 +1764,6 @@ static int launch_render_impl(const float* vertex, const float* tri, const float
     else
         rc = fused ? launch_resolve<256, true>(a, nbins, g.lds, stream) : launch_resolve<256, false>(a, nbins, g.lds, stream);
     if (rc != FR_OK) return rc;
-    return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
-}
-
-// ---- pipelined render: emit of the NEW batch beside resolve of the PREVIOUS one, in one launch ---------------------------------
-// Rows per strip of the pipelined route: the resolve role's keys must fit LEAN_KEYS_BYTES (it lives in one emit workgroup's
-// LDS), a strip must hold the 8x4 hit window and two buckets per strip must fit the offset table.  0 = not served.
-static int pipelined_rows(int H, int W) {
-    if (H <= 0 || W <= 0) return 0;
-    int rows = (int)(fr::LEAN_KEYS_BYTES / ((size_t)W * sizeof(unsigned long long)));
-    if (rows > H) rows = H;
-    if (rows < 1) return 0;
-    const int strips = (H + rows - 1) / rows;
-    if ((rows < fr::SMALL_H && strips > 1) || strips > fr::MAX_STRIPS || H > 0xFFFF || W > 0xFFFF) return 0;
-    return rows;
-}
-int fr_render_pipelined_supported_impl(int B, int ntri, int H, int W) {
-    if (B <= 0 || ntri <= 0) return 0;
-    const int rows = pipelined_rows(H, W);
-    if (!rows) return 0;
-    const RenderGeom g = render_geom(B, ntri, H, W, rows);
-    return (g.binned_ok && g.rows == rows && g.nseg <= fr::LEAN_BLOCK && fr::opt(fr::OPT_RENDER_IMPL) != 1 &&
-            (long long)B * g.nseg + (long long)B * g.strips <= 0x7FFFFFFFll) ? 1 : 0;
-}
-
-// phases: 4 = pack the triangle list into ws_new, 1 = emit the new batch (vertex -> ws_new), 2 = resolve the previous batch
-// (ws_prev -> planes).  1 | 2 together are ONE launch (render_fused_kernel); alone they are the stand-alone kernels on the same
-// strip geometry (the first step of a stream has nothing to resolve, the last nothing to emit).
-int fr_launch_render_pipelined(const float* vertex, const float* vertex_prev, long long vpitch, const float* tri,
-                               const float* texture, int B, int nver, int ntri, int H, int W, int tex_batch, float* depth,
-                               float* tex_img, float* normal, float* tri_ind, void* ws_new, void* ws_prev, size_t ws_bytes,
-                               hipStream_t stream, int phases) {
-    using namespace fr;
-    if (!fr_render_pipelined_supported_impl(B, ntri, H, W) || nver <= 0) return FR_ERR_UNSUPPORTED;
-    const int rows = pipelined_rows(H, W);
-    RenderArgs ae, ar;
-    RenderGeom g, g2;
-    bool binned = false;
-    int rc = FR_OK;
-    if (phases & 5) {
-        rc = prepare_render(vertex, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr, nullptr,
-                            nullptr, ws_new, ws_bytes, vpitch, ae, g, &binned, rows);
-        if (rc != FR_OK) return rc;
-        if (!binned) return FR_ERR_UNSUPPORTED;
-    }
-    if (phases & 2) {
-        // (the resolver rasterises "big" records itself: it needs the vertices of ITS batch, which the new batch's decode
-        // must not have overwritten -- hence a vertex hand-off buffer per batch in flight)
-        rc = prepare_render(vertex_prev, tri, texture, B, nver, ntri, H, W, tex_batch, depth, tex_img, normal, tri_ind, nullptr,
-                            nullptr, nullptr, ws_prev, ws_bytes, vpitch, ar, g2, &binned, rows);
-        if (rc != FR_OK) return rc;
-        if (!binned) return FR_ERR_UNSUPPORTED;
-        g = g2;
-    }
-    const long long n_emit = (long long)B * g.nseg, n_res = (long long)B * g.strips;
-    if (phases & 4) {
-        int4* tri4 = const_cast<int4*>(ae.tri4);
-        hipLaunchKernelGGL(pack_tri_kernel, dim3((unsigned)g.nseg), dim3(256), 0, stream, tri, nver, ntri, tri4,
-                           tri4 + (size_t)g.nseg * SEG, tri4 + (size_t)g.nseg * SEG + 1, opt(OPT_EMIT_ORDER));
-    }
-    const bool alone = opt(OPT_FUSED_ALONE) != 0 && (phases & 3) != 0;   // probe: a single role through the fused kernel
-    if ((phases & 3) == 3 || alone) {
-        FusedArgs f;
-        f.e = (phases & 1) ? ae : ar;
-        f.r = (phases & 2) ? ar : ae;
-        f.n_emit = (phases & 1) ? (int)n_emit : 0;
-        f.n_res = (phases & 2) ? (int)n_res : 0;
-        f.order = opt(OPT_FUSED_ORDER);
-        {
-            const long long nminor = f.n_res <= f.n_emit ? f.n_res : f.n_emit, nmajor = f.n_res <= f.n_emit ? f.n_emit : f.n_res;
-            f.minor_is_res = f.n_res <= f.n_emit ? 1 : 0;
-            f.grp_q = nminor > 0 ? (int)(nmajor / nminor) : 0;
-            f.grp_rem = nminor > 0 ? (int)(nmajor % nminor) : 0;
-            // v / d == umulhi(v, ceil(2^32 / d)) while v * (magic * d - 2^32) < 2^32: magic * d - 2^32 < d, so v * d < 2^32 is enough
-            const unsigned long long d1 = (unsigned long long)f.grp_q + 2, d2 = (unsigned long long)f.grp_q + 1;
-            if (f.grp_q > 0 && (unsigned long long)(nminor + nmajor) * d1 < 0x100000000ull) {
-                f.grp_magic_long = (uint32_t)((0x100000000ull + d1 - 1) / d1);
-                f.grp_magic_short = d2 > 1 ? (uint32_t)((0x100000000ull + d2 - 1) / d2) : 0u;
-                if (d2 == 1) f.grp_q = 0;   // (q == 0 cannot happen here; keeps the reciprocal of 1 out of the kernel)
-            } else {
-                f.grp_q = 0;                // out of the reciprocals' range (or a role with no blocks): resolve blocks first
-                f.grp_magic_long = f.grp_magic_short = 0;
-            }
-        }
-        hipLaunchKernelGGL(render_fused_kernel, dim3((unsigned)(f.n_emit + f.n_res)), dim3(LEAN_BLOCK), 0, stream, f);
-    } else if (phases & 1) {
-        hipLaunchKernelGGL(raster_emit_kernel<NoEmitProbe>, dim3((unsigned)n_emit), dim3(EMIT_BLOCK), 0, stream, ae);
-    } else if (phases & 2) {
-        rc = launch_resolve<256, false>(ar, n_res, g.lds, stream);
-        if (rc != FR_OK) return rc;
-    }
     return hipGetLastError() == hipSuccess ? FR_OK : FR_ERR_LAUNCH;
 }
 

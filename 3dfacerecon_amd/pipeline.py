@@ -33,12 +33,14 @@ def _host():
 
 
 class DecodeRenderPlan:
-    def __init__(self, net, batch, height=None, width=None, texture=None, stream=None):
+    def __init__(self, net, batch, height=None, width=None, texture=None, stream=None, strip_rows=0):
         """net: nets.network.FaceRecNet (holds the packed basis, tri, vertex_code); texture: (3,N) or (B,3,N)
         tensor, default net.vertex_code (the PNCC colour code, reference network.py:116).  stream: a torch.cuda.Stream
-        every launch of this plan goes to (default: whatever torch's current stream is at the call)."""
+        every launch of this plan goes to (default: whatever torch's current stream is at the call).  strip_rows: rows per
+        screen strip of the resolver (FR_PHASES_STRIP_ROWS in include/fr_hotpath.h; 0 = the library's choice)."""
         h = _host()
         self.stream = stream
+        self.strip_rows = int(strip_rows) & 0xFF
         self._h = h
         self._L = L = h.lib()
         self.net = net
@@ -99,7 +101,7 @@ class DecodeRenderPlan:
 
     def _run(self, phases):
         """Phase bits of fr_decode_render_forward: 8 = decode, 4 = pack the triangle list, 1 = emit, 2 = resolve."""
-        rc = self._fused_fn(*self._fused_args, self._stream(), phases)
+        rc = self._fused_fn(*self._fused_args, self._stream(), phases | (self.strip_rows << 8))
         if rc:
             self._h.check(rc, self._fused_name)
 
@@ -231,10 +233,13 @@ class BatchesInFlight:
     slot comes round again (S submits later).  `submit(params)` copies `params` into the slot's buffer on the slot's stream
     after making that stream wait for torch's current stream (the producer of `params`)."""
 
-    def __init__(self, net, batch, height=None, width=None, texture=None, slots=2):
+    def __init__(self, net, batch, height=None, width=None, texture=None, slots=2, strip_rows=None):
         if int(slots) < 1:
             raise ValueError("slots must be >= 1")
         self.device = net.device
+        if strip_rows is None:
+            strip_rows = self.strip_rows_in_flight(net, batch, height, width) if int(slots) > 1 else 0
+        self.strip_rows = int(strip_rows)
         with torch.cuda.device(self.device):
             self.slots = []
             for i in range(int(slots)):
@@ -242,10 +247,24 @@ class BatchesInFlight:
                 # through this API): slot 0 runs at HIGH priority, the others at NORMAL -- one batch entitled to run ahead, the
                 # other filling in (profiles/round4_probes/r4p: equal priorities sometimes lock the streams into step)
                 st = torch.cuda.Stream(device=self.device, priority=(-1 if i == 0 else 0))
-                self.slots.append(_Slot(net, batch, height, width, texture, stream=st))
+                self.slots.append(_Slot(net, batch, height, width, texture, stream=st, strip_rows=self.strip_rows))
             torch.cuda.synchronize(self.device)   # every slot's triangle table is packed before anything else touches the slots
         self._next = 0
         self.B = self.slots[0].B
+
+    @staticmethod
+    def strip_rows_in_flight(net, batch, height=None, width=None):
+        """The resolver's strip height for plans that run BESIDE another batch: four fifths of the library's own choice where that
+        is ten rows or more (200 x 200 at 64 faces: 8 instead of 10 -- 1,600 resolver workgroups instead of 1,280 fill the other
+        batch's gaps better: -0.9 us per batch with two in flight, +1.3 us one batch at a time, profiles/round4_probes/r4q,
+        round6_probes/r6e), otherwise 0 = no hint.  A scheduling hint: no result bit depends on it."""
+        h = _host()
+        H = int(net.im_size if height is None else height)
+        W = int(net.im_size if width is None else width)
+        geom = (ctypes.c_int * 4)()
+        h.lib().fr_debug_render_geom(int(batch), int(net.tri.shape[1]), H, W, 0, geom)
+        rows = int(geom[0])
+        return (4 * rows) // 5 if rows >= 10 else 0
 
     def submit(self, params=None, marks=None):
         """Launches decode + render of one batch on the next slot's stream; returns the slot (a DecodeRenderPlan).
@@ -284,118 +303,3 @@ class _Slot(DecodeRenderPlan):
 
     def make_current_stream_wait(self):
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
-
-
-class PipelinedPlan:
-    """The same hot path with TWO batches in flight (fr_decode_render_pipelined): `submit()` decodes batch k and runs its
-    emit phase beside the resolve phase of batch k-1 in ONE launch (the two kernels bind on different units of the chip:
-    vector issue vs the store path), so the planes of batch k-1 come out of step k; `flush()` resolves the last batch.
-    Per step: two launches (decode, fused emit || resolve) instead of three.  Every batch in flight owns a render workspace
-    and a vertex hand-off buffer; the four output planes are single-buffered (only the resolve role writes them): what
-    `submit()` / `flush()` return is overwritten by the next call.  The planes are bit-identical to DecodeRenderPlan.step()
-    on the same parameters.  Forward only."""
-
-    def __init__(self, net, batch, height=None, width=None, texture=None):
-        h = _host()
-        self._h = h
-        self._L = L = h.lib()
-        self.net = net
-        self.device = net.device
-        self.B = int(batch)
-        self.H = int(net.im_size if height is None else height)
-        self.W = int(net.im_size if width is None else width)
-        self.N = net.nvert
-        self.T = int(net.tri.shape[1])
-        if net._basis.use_q30():
-            raise ValueError("PipelinedPlan runs the f32 decode only")
-        if not L.fr_decode_render_pipelined_supported(self.B, self.N, self.T, self.H, self.W):
-            raise ValueError("fr_decode_render_pipelined does not serve B=%d, %dx%d: use DecodeRenderPlan"
-                             % (self.B, self.H, self.W))
-        f32 = dict(dtype=torch.float32, device=self.device)
-        self.params = torch.zeros((self.B, net.ndim), **f32)
-        self.depth = torch.empty((self.B, self.H, self.W, 1), **f32)
-        self.texture_image = torch.empty((self.B, self.H, self.W, 3), **f32)
-        self.normal = torch.empty((self.B, self.H, self.W, 3), **f32)
-        self.tri_ind = torch.empty((self.B, self.H, self.W, 1), **f32)
-        tex = net.vertex_code if texture is None else h.require_gpu_f32(texture, "texture")
-        self.texture = tex.contiguous()
-        self.tex_batch = 1 if self.texture.dim() == 2 else int(self.texture.shape[0])
-        if self.tex_batch not in (1, self.B) or self.texture.shape[-2] != 3 or self.texture.shape[-1] != self.N:
-            raise ValueError("texture must be (3,N), (1,3,N) or (B,3,N)")
-        self._ws_bytes = L.fr_render_depth_workspace_bytes(self.B, self.N, self.T, self.H, self.W)
-        self._ws = [torch.empty((max(self._ws_bytes, 16),), dtype=torch.uint8, device=self.device) for _ in range(2)]
-        self.pitch = int(L.fr_decode_render_vertex_pitch(self.N))
-        self._vertex = [torch.empty((self.B, 3, self.pitch), **f32) for _ in range(2)]
-        self._vertex_bytes = self._vertex[0].numel() * 4
-        self.q30 = False
-        self._slot = 0          # buffers the NEXT submitted batch takes
-        self._pending = False   # a submitted batch waits for its resolve
-        self.pack_tri()
-
-    def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-
-    def _run(self, phases, new, prev):
-        p = self._h.ptr
-        net = self.net
-        rc = self._L.fr_decode_render_pipelined(
-            p(self.params), p(net._basis.image), None, p(net.tri), p(self.texture), self.B, self.N, net.ndim_shape,
-            net.ndim_exp, self.T, self.H, self.W, self.tex_batch, ctypes.c_float(float(net.im_size)), p(self._vertex[new]),
-            p(self._vertex[prev]), self._vertex_bytes, p(self.depth), p(self.texture_image), p(self.normal), p(self.tri_ind),
-            p(self._ws[new]), p(self._ws[prev]), self._ws_bytes, self._stream(), phases)
-        if rc:
-            self._h.check(rc, "fr_decode_render_pipelined")
-
-    def pack_tri(self):
-        """(Re)builds the pre-validated triangle table in BOTH workspaces; call again after changing net.tri in place
-        (with nothing pending)."""
-        with torch.cuda.device(self.device):
-            self._run(4, 0, 1)
-            self._run(4, 1, 0)
-
-    def outputs(self):
-        return self.depth, self.texture_image, self.normal, self.tri_ind
-
-    @property
-    def vertex_proj(self):
-        """[B,3,N] strided view of the vertices of the batch submitted LAST (the one whose planes come out next)."""
-        return self._vertex[self._slot ^ 1][:, :, :self.N]
-
-    def submit(self, params=None):
-        """Decode + emit of a new batch, beside the resolve of the pending one.  Returns the PENDING batch's four planes
-        (None for the first batch of a stream)."""
-        if params is not None:
-            self.params.copy_(params.reshape(self.B, -1), non_blocking=True)
-        new, prev = self._slot, self._slot ^ 1
-        had = self._pending
-        self._run(8 | 1 | (2 if had else 0), new, prev)
-        self._slot ^= 1
-        self._pending = True
-        return self.outputs() if had else None
-
-    def submit_phases(self, phases):
-        """The same step launch by launch (bench.py's event brackets): 8 = the decode, 3 = the fused emit || resolve
-        launch (the plain emit kernel when nothing is pending).  Call with 8, then with 3."""
-        new, prev = self._slot, self._slot ^ 1
-        if phases == 8:
-            self._run(8, new, prev)
-            return
-        self._run(1 | (2 if self._pending else 0), new, prev)
-        self._slot ^= 1
-        self._pending = True
-
-    def flush(self):
-        """Resolves the pending batch (the stand-alone resolve kernel on the pipelined strip geometry) -> its four planes."""
-        if not self._pending:
-            return None
-        prev = self._slot ^ 1
-        self._run(2, self._slot, prev)
-        self._pending = False
-        return self.outputs()
-
-    def step(self, params=None):
-        """One batch start to finish on the pipelined route's kernels (submit + flush: nothing overlaps) -- the
-        DecodeRenderPlan.step() contract, for callers that need the planes of THIS batch now."""
-        self.flush()
-        self.submit(params)
-        return self.flush()

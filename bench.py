@@ -155,15 +155,7 @@ def parity_gate(plan, net, assets, params_np, H, W, n_faces, run=True):
     import torch
     from oracle import oracle as O
     n = min(int(n_faces), plan.B)
-    piped = hasattr(plan, "submit")
-    if piped:
-        # the timed route: the planes checked are the ones the FUSED launch's resolve role wrote (batch 1 of two identical
-        # submits), the vertices the ones the second submit decoded (the same parameters: the same values)
-        plan.flush()
-        plan.submit()
-        plan.submit()
-        torch.cuda.synchronize(plan.device)
-    elif run:
+    if run:
         plan.step()
     torch.cuda.synchronize(plan.device)
     V = plan.vertex_proj[:n].contiguous().cpu().numpy()   # (the plan hands the vertices over in pitched rows: a strided view)
@@ -189,11 +181,7 @@ def parity_gate(plan, net, assets, params_np, H, W, n_faces, run=True):
     frac_equal = float((ulp == 0).mean())
     max_ulp = int(ulp.max())
     ok = bad_planes == 0 and bad_decode == 0 and max_ulp <= 2 and frac_equal >= 0.99
-    if piped:
-        plan.flush()
-    return {"faces": n, "route": ("PipelinedPlan (fr_decode_render_pipelined: decode, then ONE launch = emit of this batch || resolve of "
-                                  "the previous one; the planes checked come out of that launch's resolve role)") if piped else
-                                 "DecodeRenderPlan (fr_decode_render_forward, phases 8|1|2 on a triangle table packed once)",
+    return {"faces": n, "route": "DecodeRenderPlan (fr_decode_render_forward, phases 8|1|2 on a triangle table packed once)",
             "mismatching_planes": bad_planes, "planes_checked": 4 * n,
             "decode_host_rotation_mismatching_faces": bad_decode,
             "decode_inkernel_rotation": {"max_ulp": max_ulp, "frac_bit_equal": frac_equal, "bar": "<= 2 ulp, >= 0.99 equal"},
@@ -278,13 +266,16 @@ def main():
                     help="faces per rank the oracle checks before the line is printed (-1 = all of them; 0 = skip, the "
                          "line then carries parity = null and must not be quoted)")
     ap.add_argument("--no-ops-surface", action="store_true", help="skip the operator-surface leg")
-    ap.add_argument("--route", choices=("auto", "inflight", "pipelined", "serial"), default="auto",
+    ap.add_argument("--route", choices=("auto", "inflight", "serial"), default="auto",
                     help="inflight: BatchesInFlight (--in-flight independent batches, each on its own stream, no edge between "
                          "them: consecutive steps go to alternating slots); serial: DecodeRenderPlan (one batch at a time, three "
-                         "launches per batch on one stream); pipelined: PipelinedPlan (decode, then emit(k) || resolve(k-1) in "
-                         "one launch; measured slower, DESIGN.md 4.6).  auto = inflight (measured fastest, DESIGN.md 4.7)")
+                         "launches per batch on one stream).  auto = inflight (measured fastest, DESIGN.md 4.7)")
     ap.add_argument("--in-flight", type=int, default=2, help="slots of the inflight route (2 measured best; 3 is slower again)")
-    ap.add_argument("--no-serial-leg", action="store_true", help="skip the serial plan's comparison leg (inflight / pipelined routes)")
+    ap.add_argument("--strip-rows", type=int, default=-1,
+                    help="inflight route: rows per screen strip of the resolver in the slots' plans (FR_PHASES_STRIP_ROWS).  -1 = "
+                         "pipeline.BatchesInFlight's own choice (8 where the library alone picks 10: smaller resolver workgroups fill "
+                         "the other batch's gaps), 0 = the library's choice, n = n rows.  No result bit depends on it")
+    ap.add_argument("--no-serial-leg", action="store_true", help="skip the serial plan's comparison leg (inflight route)")
     ap.add_argument("--q30-levels", type=int, default=4, choices=(0, 4, 5, 7),
                     help="also time the in-flight route with the Q30 decode (int8 matrix cores) at this many digit-product "
                          "levels, parity-gated against ITS oracle, and report it beside `value` as `q30_inflight` (0 = skip; "
@@ -346,23 +337,14 @@ def main():
     else:
         params_np = synth.sample_params_batch(B, im_size=H, beta=0.7, seed=3456 + rank)
     L = pkg("_lib").lib()
-    piped_ok = bool(L.fr_decode_render_pipelined_supported(B, net.nvert, int(net.tri.shape[1]), H, W)) and not net._basis.use_q30()
-    if args.route == "pipelined" and not piped_ok:
-        raise SystemExit("bench.py --route pipelined: fr_decode_render_pipelined does not serve this shape / arithmetic")
-    # auto = the faster route on this hardware: the serial plan (the fused emit || resolve launch measured 112-120 us per step
-    # against 111 us: the two roles bind on the same per-CU vector-memory path and do not overlap)
-    piped = piped_ok and args.route == "pipelined"
     inflight = args.route in ("auto", "inflight")
     serial_plan = pipe.DecodeRenderPlan(net, B, H, W)
     serial_plan.params.copy_(torch.as_tensor(params_np, device=dev))
     plan = serial_plan
     slot_params = [params_np]
-    if piped:
-        plan = pipe.PipelinedPlan(net, B, H, W)
-        plan.params.copy_(torch.as_tensor(params_np, device=dev))
-    elif inflight:
+    if inflight:
         # every slot its own batch: slot 0 the rank's batch above, slot i another draw of the same sampler
-        plan = pipe.BatchesInFlight(net, B, H, W, slots=max(1, args.in_flight))
+        plan = pipe.BatchesInFlight(net, B, H, W, slots=max(1, args.in_flight), strip_rows=(None if args.strip_rows < 0 else args.strip_rows))
         for i in range(1, len(plan.slots)):
             if args.scaling == "strong":
                 slot_params.append(synth.sample_params_batch(args.batch, im_size=H, beta=0.7, seed=3456 + 1000 * i)[first:first + B])
@@ -383,20 +365,15 @@ def main():
     # The timed region -- EXACTLY K steps between barrier + synchronize brackets -- is run R times back to back and the
     # MEDIAN block is reported (min / max alongside): at ~0.11 ms per step a single K = 20 block is 2.2 ms of wall clock,
     # short enough for clock ramps and host jitter to move it by several per cent.
-    # Pipelined route: a block is K submits + the drain -- K batches go from parameters to planes INSIDE the brackets (the
-    # first step's launch has no previous batch to resolve, the drain resolves the last one: fill and drain are paid in
-    # every block, nothing is carried in from the warm-up or left for later).
     # Per-kernel durations are taken live, inside the timed regions, with HIP events on the launch stream -- on every
     # EV_EVERY-th step only: an event pair costs a few microseconds of stream bubble, which at ~110 us per step would
     # otherwise tax every step by ~7 %.
     EV_EVERY, EV_FIRST = 10, 5   # steps 5, 15, 25, ...: never the block's first step (it starts on an idle chip)
 
-    def timed_blocks(pl, is_piped, with_events):
+    def timed_blocks(pl, with_events):
         is_fl = hasattr(pl, "slots")
         for _ in range(Wm):
-            pl.submit() if (is_piped or is_fl) else pl.step()
-        if is_piped:
-            pl.flush()
+            pl.submit() if is_fl else pl.step()
         # (events for every block are created up front and the per-block max over ranks is taken after the last block, so
         # that the host does nothing but barrier + synchronize + clock reads between two timed regions)
         evs = [({k: [torch.cuda.Event(enable_timing=True) for _ in range(4)] for k in range(min(EV_FIRST, K - 1), K, EV_EVERY)}
@@ -412,13 +389,7 @@ def main():
                 if is_fl:        # step k goes to slot k mod S, on that slot's stream; the events are recorded on that stream
                     pl.submit(marks=e)
                 elif e is None:
-                    pl.submit() if is_piped else pl.step()
-                elif is_piped:   # the same two launches, each bracketed by events
-                    e[0].record()
-                    pl.submit_phases(8)
-                    e[1].record()
-                    pl.submit_phases(3)
-                    e[2].record()
+                    pl.step()
                 else:            # the same three kernels, each bracketed by events (the render op launched phase by phase)
                     e[0].record()
                     pl.decode()
@@ -427,8 +398,6 @@ def main():
                     e[2].record()
                     pl.render_phase(2)
                     e[3].record()
-            if is_piped:
-                pl.flush()
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             dist_u.barrier()
@@ -439,7 +408,7 @@ def main():
         med = order[(R - 1) // 2]              # the median block (lower median for an even R)
         return blk, blk[med], loc[med], ev_all
 
-    blocks, elapsed, local_med, ev_all = timed_blocks(plan, piped, True)
+    blocks, elapsed, local_med, ev_all = timed_blocks(plan, True)
     clocks = {"after_timed_blocks": clock_probe(L, dev)}   # (straight behind the last timed block: the chip is as warm as it gets)
     per_rank_ms = [1e3 * t / K for t in dist_u.gather_over_ranks(local_med, device=dev)]
     dist_info = dist_u.describe(device=dev)
@@ -448,8 +417,8 @@ def main():
     # the serial plan (three launches per batch, nothing in flight across batches) in the same process, same K / W / R
     serial_elapsed = None
     serial_ev = []
-    if (piped or inflight) and not args.no_serial_leg:
-        _, serial_elapsed, _, serial_ev = timed_blocks(serial_plan, False, inflight)
+    if inflight and not args.no_serial_leg:
+        _, serial_elapsed, _, serial_ev = timed_blocks(serial_plan, True)
         clocks["after_serial_leg"] = clock_probe(L, dev)
 
     # the same in-flight route with the Q30 decode (int8 matrix cores, `--q30-levels` digit-product levels): its own plans,
@@ -465,14 +434,14 @@ def main():
         try:
             if os.environ.get("FR_BENCH_Q30_FAULT"):   # (tests/test_bench_gpu.py: the leg's failure path)
                 raise RuntimeError("FR_BENCH_Q30_FAULT is set: the Q30 leg fails on purpose")
-            qplan = pipe.BatchesInFlight(net, B, H, W, slots=max(1, args.in_flight))
+            qplan = pipe.BatchesInFlight(net, B, H, W, slots=max(1, args.in_flight), strip_rows=(None if args.strip_rows < 0 else args.strip_rows))
             for sl, pn in zip(qplan.slots, slot_params):
                 sl.params.copy_(torch.as_tensor(pn, device=dev))
             qserial = pipe.DecodeRenderPlan(net, B, H, W)
             qserial.params.copy_(torch.as_tensor(params_np, device=dev))
             torch.cuda.synchronize(dev)
-            qblocks, qelapsed, _, _ = timed_blocks(qplan, False, True)    # (event-bracketed steps like the f32 leg: equal treatment)
-            _, qs_elapsed, _, qs_ev = timed_blocks(qserial, False, True)
+            qblocks, qelapsed, _, _ = timed_blocks(qplan, True)    # (event-bracketed steps like the f32 leg: equal treatment)
+            _, qs_elapsed, _, qs_ev = timed_blocks(qserial, True)
             qpar = None
             if args.parity_faces != 0:
                 for _ in range(3 * len(qplan.slots)):
@@ -540,12 +509,6 @@ def main():
             parity["ok"] = bool(all(q["ok"] for q in per_slot))
         else:
             parity = parity_gate(plan, net, assets, params_np, H, W, nf)
-        if piped:   # and the two routes against each other: every plane of every face, bit for bit
-            serial_plan.step()
-            plan.step()
-            torch.cuda.synchronize(dev)
-            parity["planes_identical_to_serial_plan"] = bool(all(torch.equal(a, b) for a, b in zip(plan.outputs(), serial_plan.outputs())))
-            parity["ok"] = bool(parity["ok"] and parity["planes_identical_to_serial_plan"])
         all_ok = dist_u.sum_over_ranks(0.0 if parity["ok"] else 1.0, device=dev) == 0.0
         parity["faces_all_ranks"] = int(round(dist_u.sum_over_ranks(parity["faces"], device=dev)))
         parity["mismatching_planes_all_ranks"] = int(round(dist_u.sum_over_ranks(parity["mismatching_planes"], device=dev)))
@@ -557,15 +520,10 @@ def main():
             sys.exit(3)
     decode_ms = sum(e[0].elapsed_time(e[1]) for e in ev_all) / len(ev_all)
     in_region = None
-    if piped:
-        fused_ms = sum(e[1].elapsed_time(e[2]) for e in ev_all) / len(ev_all)
-        emit_ms = resolve_ms = None
-    else:
-        emit_ms = sum(e[1].elapsed_time(e[2]) for e in ev_all) / len(ev_all)
-        resolve_ms = sum(e[2].elapsed_time(e[3]) for e in ev_all) / len(ev_all)
-        fused_ms = None
+    emit_ms = sum(e[1].elapsed_time(e[2]) for e in ev_all) / len(ev_all)
+    resolve_ms = sum(e[2].elapsed_time(e[3]) for e in ev_all) / len(ev_all)
     # one batch's parameters-to-planes time inside the timed region (event before its decode -> event behind its resolve)
-    latency_ms = (sum(e[0].elapsed_time(e[3]) for e in ev_all) / len(ev_all)) if not piped else None
+    latency_ms = sum(e[0].elapsed_time(e[3]) for e in ev_all) / len(ev_all)
     serial_latency_ms = (sum(e[0].elapsed_time(e[3]) for e in serial_ev) / len(serial_ev)) if serial_ev else None
     cov = float(((plan.slots[0] if inflight else plan).tri_ind >= 0).float().mean().item())
     if inflight and serial_ev:
@@ -669,22 +627,12 @@ def main():
                                "matrix-pipe utilisation and hbm_frac_of_8TBs as the HBM roofline fraction.  THE STEP is priced "
                                "under `roofline.step`"}
         kernels = {"decode": roof_decode}
-        if piped:
-            render_bytes = emit_bytes + resolve_bytes
-            kernels["render_fused"] = {
-                "bound": "hbm", "kernel": "render_fused_kernel (fr_decode_render_pipelined, phases 1|2: emit role of this batch "
-                                          "|| lean resolve role of the previous batch)",
-                "achieved": render_bytes / (fused_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                "avg_ms": fused_ms, "algorithmic_bytes_per_launch": render_bytes,
-                "algorithmic_bytes_are": "the render op's (SURVEY.md 8d): vertices + triangle list + texture read by the emit "
-                                         "role, the four planes written by the resolve role"}
-        else:
-            kernels["raster_emit"] = {"bound": "hbm", "kernel": "raster_emit_kernel (fr_decode_render_forward, phase 1)",
-                                      "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "traffic": None, "avg_ms": emit_ms, "algorithmic_bytes_per_launch": emit_bytes}
-            kernels["resolve_write"] = {"bound": "hbm", "kernel": "resolve_write_kernel<256> (fr_decode_render_forward, phase 2)",
-                                        "achieved": resolve_bytes / (resolve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "traffic": None, "avg_ms": resolve_ms, "algorithmic_bytes_per_launch": resolve_bytes}
+        kernels["raster_emit"] = {"bound": "hbm", "kernel": "raster_emit_kernel (fr_decode_render_forward, phase 1)",
+                                  "achieved": emit_bytes / (emit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "traffic": None, "avg_ms": emit_ms, "algorithmic_bytes_per_launch": emit_bytes}
+        kernels["resolve_write"] = {"bound": "hbm", "kernel": "resolve_write_kernel<256> (fr_decode_render_forward, phase 2)",
+                                    "achieved": resolve_bytes / (resolve_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "traffic": None, "avg_ms": resolve_ms, "algorithmic_bytes_per_launch": resolve_bytes}
         # HBM traffic per launch + the rocprofv3 kernel averages, from the committed profile passes of this same command
         # (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc passes; ONE stated correction for all
         # kernels -- see its `correction` field -- so the figures of one line are comparable)
@@ -702,16 +650,12 @@ def main():
             if in_region is not None and name in in_region:
                 r["in_region_avg_ms"] = in_region[name]
         dominant = max(kernels.values(), key=lambda r: r["avg_ms"])  # the kernel with the longest average launch
-        if not piped:
-            render_ms = emit_ms + resolve_ms
-            kernels["render_op"] = {"bound": "hbm", "kernel": "fr_render_depth_forward (both kernels)", "avg_ms": render_ms,
-                                    "achieved": ab["render"] * B / (render_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": ab["render"] * B / (render_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "algorithmic_bytes_per_launch": ab["render"] * B}
-        route = ("pipelined: PipelinedPlan / fr_decode_render_pipelined -- per step TWO launches: decode(k), then ONE launch "
-                 "whose blocks are the emit role of batch k or the (lean) resolve role of batch k-1; a timed block = K "
-                 "submits + the drain, so K batches go from parameters to planes inside the brackets") if piped else \
-                ("inflight: BatchesInFlight -- %d independent batches in flight, each slot a DecodeRenderPlan "
+        render_ms = emit_ms + resolve_ms
+        kernels["render_op"] = {"bound": "hbm", "kernel": "fr_render_depth_forward (both kernels)", "avg_ms": render_ms,
+                                "achieved": ab["render"] * B / (render_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": ab["render"] * B / (render_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_launch": ab["render"] * B}
+        route = ("inflight: BatchesInFlight -- %d independent batches in flight, each slot a DecodeRenderPlan "
                  "(fr_decode_render_forward, three launches per batch) on its own stream with no edge between the streams; step k "
                  "goes to slot k mod %d; a timed block = K such steps, i.e. K batches from parameters to planes between the "
                  "brackets (both streams drained at either bracket)" % (len(plan.slots), len(plan.slots))) if inflight else \
@@ -721,7 +665,7 @@ def main():
             "value": value, "unit": "faces/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": args.scaling,
             "repeats": R, "value_is": "median over %d timed blocks of K steps each" % R, "route": route,
-            "value_route": "inflight" if inflight else ("pipelined" if piped else "serial"),
+            "value_route": "inflight" if inflight else "serial",
             "value_meaning": ("THROUGHPUT of independent batches: K batches go from parameters to planes between the brackets with "
                               "%d in flight at any time; ms_per_step is the interval between finished batches, NOT one batch's "
                               "latency (per_batch_latency_ms).  A dependent loop (CoarseNet -> render -> CoarseNet, "
@@ -746,8 +690,10 @@ def main():
                                    "%dx%d, fp32, all four output planes" % (args.batch, H, W),
                        "faces_per_gpu": B if args.scaling == "weak" else None, "faces_per_step_all_gpus": faces_per_step,
                        "value_one_batch_at_a_time": (faces_per_step * K / serial_elapsed) if serial_elapsed is not None else
-                                                    (value if not (inflight or piped) else None),
-                       "faces_per_gpu_rank0": B, "batches_in_flight": len(plan.slots) if inflight else (2 if piped else 1), "nver": N, "ntri": T, "n_shape": net.ndim_shape, "n_exp": net.ndim_exp,
+                                                    (value if not inflight else None),
+                       "faces_per_gpu_rank0": B, "batches_in_flight": len(plan.slots) if inflight else 1,
+                       "resolver_strip_rows": ({"in_flight_slots": plan.strip_rows or "library default", "serial_plan": "library default"}
+                                               if inflight else "library default"), "nver": N, "ntri": T, "n_shape": net.ndim_shape, "n_exp": net.ndim_exp,
                        "sampler": "sample_test.py:23-38 beta=0.7 " + ("seed=3456+rank" if args.scaling == "weak" else "seed=3456, one batch for all ranks"), "coverage": cov,
                        "sharding": ("weak: every rank runs its own %d faces" % B if args.scaling == "weak" else
                                     "strong: ONE %d-face batch cut into contiguous shards (utils.dist.shard_range)" % args.batch)
@@ -799,7 +745,7 @@ def main():
         # ---- everything a reader needs to recompute the line's fractions, INSIDE `roofline` (the object the driver's record keeps):
         #      the dominant kernel's own fields (above), the other kernels in short, the whole step, the Q30 step, the clock ----
         per_gpu = value / world
-        serial_v = (faces_per_step * K / serial_elapsed) if serial_elapsed is not None else (value if not (inflight or piped) else None)
+        serial_v = (faces_per_step * K / serial_elapsed) if serial_elapsed is not None else (value if not inflight else None)
         step = {"what": "the WHOLE step (decode -> emit -> resolve) against the HBM roofline: algorithmic bytes per face (SURVEY.md 8d: "
                         "basis / B + params + 2 x vertices + (triangles + texture) / B + four planes) x faces/s per GPU / 8 TB/s",
                 "algorithmic_bytes_per_face": ab["pipeline"], "faces_per_step_per_gpu": B, "route": out["value_route"],

@@ -51,8 +51,6 @@ const char* fr_strerror(int code);
  *   records in registers | 0 = two-pass resolver)   FR_EMIT_FILTER (bits 0-1, default 3)   FR_RENDER_IMPL (0 | 1 = "scan": strip-scan fallback)
  *   FR_RESOLVE_BLOCK (0 = auto | 256 | 512 | 1024)   FR_RENDER_ROWS (0 = auto | rows per screen strip)
  *   FR_DECODE_STORE (0 | 1 = transposed accumulators, one dword per lane per store: measured +1.1 us, A/B only)
- *   FR_FUSED_ORDER (resolve blocks of the pipelined entry's fused launch: 0 = spread evenly | 1 = first | 2 = last)
- *   FR_FUSED_ALONE (0 | 1 = probe: a lone emit / resolve phase of the pipelined entry also runs through the fused kernel)
  *   FR_BWD_CHUNKS (row chunks of the packed decode-backward GEMM: 256 = default | 1 .. 512; changes the association of the
  *   partial sums, i.e. the gradient's last bits -- every other knob leaves every result bit unchanged)
  *   FR_BWD_CB (16-coefficient blocks per wave of the fused decode backward: 0 = by batch | 2 | 4)
@@ -176,7 +174,14 @@ int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R
  * 4-byte phase and every 64-byte piece straddles two lines; measured -2.7 us per 64-face decode).  Element (b, c, p) sits at
  * (b * 3 + c) * pitch + p, so a strided view of the buffer IS the [B,3,N] tensor (the pad floats are never written or read).
  *   phases: bit 8 = decode, bit 4 = pack the triangle list, bit 1 = emit, bit 2 = resolve (15 = everything; a caller whose
- *   triangle list is a model constant runs 4 once and 11 per batch).  Results are bit-identical to the two separate calls. */
+ *   triangle list is a model constant runs 4 once and 11 per batch).  Results are bit-identical to the two separate calls.
+ *   FR_PHASES_STRIP_ROWS(n) (bits 8-15 of `phases`, 0 = the library's choice): rows per screen strip of the resolver, i.e. how many
+ *   resolver workgroups the screen is cut into -- a scheduling hint with no effect on any result bit or workspace size, to be
+ *   passed unchanged with every phase of the same workspace.  The library's own choice (10 rows at 64 faces of 200 x 200) is the
+ *   fastest one batch at a time; a caller that keeps two batches in flight on two streams does better with 8 (-0.9 us per
+ *   batch: smaller resolver workgroups fill the other batch's gaps; +1.3 us one at a time).  A hint the binned rasteriser does not
+ *   serve is ignored. */
+#define FR_PHASES_STRIP_ROWS(n) (((n) & 0xFF) << 8)
 int fr_decode_render_vertex_pitch(int N);
 size_t fr_decode_render_vertex_bytes(int B, int N);
 int fr_decode_render_forward(const float* params, const void* packed_basis, const float* R_override, const float* tri,
@@ -185,25 +190,9 @@ int fr_decode_render_forward(const float* params, const void* packed_basis, cons
                              float* tex_img, float* normal, float* tri_ind, void* workspace, size_t ws_bytes,
                              void* hip_stream, int phases);
 
-/* The same step, PIPELINED over consecutive batches (replaces the serial batch loop render_depth_op.cc:180-316 across two
- * calls of the op): the rasteriser's two kernels bind on different units (emit: vector issue; resolve: the store path), so the
- * emit of batch k runs beside the resolve of batch k-1 as two ROLES of one launch, chosen by block index -- every block
- * depends only on earlier launches, so there is no event, fence or intra-launch dependency.  Each batch in flight needs its
- * own render workspace (fr_render_depth_workspace_bytes each, the triangle table packed into both) and its own vertex
- * hand-off buffer (fr_decode_render_vertex_bytes each; the resolver rasterises oversized triangles from the vertices):
- *   phases: bit 8 = decode the new batch into vertex_new, bit 4 = pack the triangle list into workspace_new,
- *   bit 1 = emit the new batch (vertex_new -> workspace_new), bit 2 = resolve the previous batch (workspace_prev, vertex_prev
- *   -> the four planes).  Bits 1 | 2 together are ONE launch; a stream of batches runs 4 once per workspace, then 8|1 for the first
- *   batch, 8|1|2 for every further one (the planes of batch k-1 come out of step k) and 2 to drain.  The planes are
- *   bit-identical to fr_decode_render_forward on the same batch (the screen is cut into narrower strips; no result depends
- *   on that).  fr_decode_render_pipelined_supported: 1 when the shape is served (a strip of at least 4 rows must fit 12,800 B
- *   of keys: W <= 400 for H > 4), else 0 and the entry point returns FR_ERR_UNSUPPORTED -- use fr_decode_render_forward. */
-int fr_decode_render_pipelined_supported(int B, int N, int ntri, int H, int W);
-int fr_decode_render_pipelined(const float* params, const void* packed_basis, const float* R_override, const float* tri,
-                               const float* texture, int B, int N, int n_shape, int n_exp, int ntri, int H, int W,
-                               int tex_batch, float im_size, float* vertex_new, const float* vertex_prev, size_t vertex_bytes,
-                               float* depth, float* tex_img, float* normal, float* tri_ind, void* workspace_new,
-                               void* workspace_prev, size_t ws_bytes, void* hip_stream, int phases);
+/* (Rounds 4-5 also exported fr_decode_render_pipelined: the emit of batch k and the resolve of batch k-1 as two roles of ONE
+ * launch.  Bit-identical, measured 5-8 % slower than this entry point in both rounds and removed in round 6; a caller
+ * that wants batches to overlap calls fr_decode_render_forward on two streams with two sets of buffers -- pipeline.BatchesInFlight.) */
 
 /* Second definition of the same decode (nothing of it is built, allocated or launched unless these entry
  * points are called):

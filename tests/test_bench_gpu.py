@@ -128,14 +128,6 @@ def test_bench_line_serial_route():
     assert d["roofline"]["step"]["one_batch_at_a_time"]["ms_per_step"] == pytest.approx(d["ms_per_step"], rel=1e-9)
 
 
-def test_bench_line_pipelined_route():
-    """--route pipelined: two launches per step (decode, fused emit || resolve); the serial plan is timed beside it and the two
-    routes' planes are compared bit for bit inside the parity gate."""
-    d = _line([sys.executable, "bench.py"] + SHORT + ["--cpu-faces", "0", "--route", "pipelined", "--no-ops-surface"])
-    assert d["route"].startswith("pipelined") and set(d["kernels"]) == {"decode", "render_fused"}
-    assert d["parity"]["ok"] and d["parity"]["planes_identical_to_serial_plan"] and d["serial_plan_faces_per_s"] > 1e4
-
-
 @pytest.mark.parametrize("scaling,global_faces,local_faces", [("weak", 128, 64), ("strong", 64, 32)])
 def test_bench_two_ranks_walk_the_multi_rank_flow(scaling, global_faces, local_faces):
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",

@@ -74,6 +74,9 @@ def test_round3_entry_points_validate_before_any_hip_call():
     args = lambda phases, hand=one, hbytes=3 * 32 * 4, B=1: (one, one, nul, one, one, B, 20, 2, 2, 5, 8, 8, 1, f, hand, hbytes,  # noqa: E731
                                                              one, one, one, one, nul, 0, nul, phases)
     assert L.fr_decode_render_forward(*args(0)) == -1 and L.fr_decode_render_forward(*args(16)) == -1      # phase bits
+    # round 6: bits 8-15 carry the strip-height hint (FR_PHASES_STRIP_ROWS); a hint without a phase, or any bit beyond, is refused
+    assert L.fr_decode_render_forward(*args(8 << 8)) == -1 and L.fr_decode_render_forward(*args(11 | 0x10000)) == -1
+    assert L.fr_decode_render_forward(*args(11 | (8 << 8), B=0)) == 0 and L.fr_decode_render_forward(*args(11 | (8 << 8), hand=nul)) == -2
     assert L.fr_decode_render_forward(*args(11, B=0)) == 0                                                  # empty batch
     assert L.fr_decode_render_forward(*args(11, hand=nul)) == -2                                            # no hand-off buffer
     assert L.fr_decode_render_forward(*args(11, hbytes=16)) == -2                                           # too small
@@ -93,6 +96,7 @@ def test_round3_entry_points_validate_before_any_hip_call():
     qargs = lambda phases, lv=4, hand=one, qws=one, qb=1 << 20, B=1: (one, q, nul, one, one, B, 20, 2, 2, 5, 8, 8, 1, f, lv, hand,  # noqa: E731
                                                                        3 * 32 * 4, one, one, one, one, nul, 0, qws, qb, nul, phases)
     assert L.fr_decode_render_forward_q30(*qargs(0)) == -1 and L.fr_decode_render_forward_q30(*qargs(11, lv=3)) == -1
+    assert L.fr_decode_render_forward_q30(*qargs(8 << 8)) == -1 and L.fr_decode_render_forward_q30(*qargs(11 | (8 << 8), B=0)) == 0
     assert L.fr_decode_render_forward_q30(*qargs(11, B=0)) == 0
     assert L.fr_decode_render_forward_q30(*qargs(11, hand=nul)) == -2
     assert L.fr_decode_render_forward_q30(*qargs(11, qws=nul, qb=0)) == -2        # no staging workspace

@@ -124,7 +124,7 @@ def test_full_size_batch64(oracle, full_assets, synth):
     np.testing.assert_array_equal(got2[:, 2], got[:, 2])
 
 
-@pytest.mark.parametrize("knobs", [{"FR_DECODE_NT": 0}, {"FR_DECODE_NBW": 1}, {"FR_DECODE_WAVES": 8}, {"FR_DECODE_IMPL": 1},
+@pytest.mark.parametrize("knobs", [{"FR_DECODE_NT": 0}, {"FR_DECODE_NT": 1}, {"FR_DECODE_NBW": 1}, {"FR_DECODE_WAVES": 8}, {"FR_DECODE_IMPL": 1},
                                    {"FR_DECODE_WIDE": 0}])
 def test_launcher_knobs_do_not_change_a_bit(oracle, synth, knobs):
     """The decode launcher's A/B knobs (fr_set_option; the environment is read once per process) select other schedules of

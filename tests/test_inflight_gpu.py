@@ -30,6 +30,9 @@ def test_batches_in_flight_bit_identical_to_the_serial_plan(full_assets, synth, 
         wantv.append(serial.vertex_proj.clone())
     torch.cuda.synchronize()
     fl = pipe.BatchesInFlight(net, B, 200, 200, slots=slots)
+    # (round 6: plans that run beside another batch ask for 8-row strips where the library alone picks 10 -- a scheduling hint,
+    # so this comparison with the serial plan's 10-row strips is also the proof that it changes no bit)
+    assert fl.strip_rows == (8 if slots > 1 else 0) and all(sl.strip_rows == fl.strip_rows for sl in fl.slots) and serial.strip_rows == 0
     # a stream of seven batches; a slot's results are collected just before the slot comes round again
     pending = {}
     got = {}
@@ -47,6 +50,27 @@ def test_batches_in_flight_bit_identical_to_the_serial_plan(full_assets, synth, 
         for g, w, n in zip(got[k][0], want[k], NAMES):
             assert torch.equal(g, w), "batch %d, %s: %d elements differ" % (k, n, int((g != w).sum()))
     assert float((want[0][3] >= 0).float().mean()) > 0.2
+
+
+@pytest.mark.parametrize("B,S,small", [(64, 200, False), (5, 96, True), (3, 37, True)])
+def test_strip_height_hint_changes_no_bit(full_assets, small_assets, synth, B, S, small):
+    """FR_PHASES_STRIP_ROWS (bits 8-15 of fr_decode_render_forward's `phases`): any strip height the binned rasteriser serves, and
+    any it does not (those are ignored), gives the planes of the library's own choice, bit for bit."""
+    dev = torch.device("cuda:0")
+    net = net_mod().FaceRecNet(mesh_data=small_assets if small else full_assets, batch_size=B, im_size=S, device=dev)
+    pipe = pkg("pipeline")
+    P = torch.as_tensor(synth.sample_params_batch(B, im_size=S, n_shape=net.ndim_shape, n_exp=net.ndim_exp, beta=0.7, seed=77), device=dev)
+    base = pipe.DecodeRenderPlan(net, B, S, S)
+    want = [t.clone() for t in base.step(P)]
+    assert float((want[3] >= 0).float().mean()) > 0.0005      # (something is on screen)
+    for rows in (8, 5, 4, 25, 2, 1, 200, 255):
+        plan = pipe.DecodeRenderPlan(net, B, S, S, strip_rows=rows)
+        got = plan.step(P)
+        torch.cuda.synchronize()
+        for g, w, n in zip(got, want, NAMES):
+            assert torch.equal(g, w), "strip_rows=%d, %s: %d elements differ" % (rows, n, int((g != w).sum()))
+    hint = pipe.BatchesInFlight.strip_rows_in_flight(net, B, S, S)
+    assert hint == 8 if (B, S) == (64, 200) else 0 <= hint <= 255
 
 
 def test_resident_parameters_many_steps_and_a_consumer_on_the_current_stream(full_assets, synth):

@@ -34,14 +34,13 @@ def kernel_stats(name, out):
                                  for r in hot}}
 
 
-for j in ("bench", "bench_again", "bench_k20", "bench_serial", "bench_pipelined", "bench_graph", "bench_q30", "bench_q30l5", "bench_q30l4",
+for j in ("bench", "bench_again", "bench_k20", "bench_serial", "bench_graph", "bench_q30", "bench_q30l5", "bench_q30l4",
           "phase_test", "inflight_timeline", "pmc_summary_q30l4"):
     f = os.path.join(src, j + ".json")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.json" % (tag, j)))
 kernel_stats("prof_bench", "%s_kernel_stats.csv" % tag)
 kernel_stats("prof_bwd", "%s_decode_bwd_kernel_stats.csv" % tag)
-kernel_stats("prof_pipelined", "%s_pipelined_kernel_stats.csv" % tag)
 kernel_stats("prof_inflight", "%s_inflight_kernel_stats.csv" % tag)
 kernel_stats("prof_q30l4", "%s_q30l4_kernel_stats.csv" % tag)
 for lg in ("bwd_probe.log", "bwd_ab.log", "legs.log", "kernel_timing.log"):

@@ -13,8 +13,8 @@ def pkg(n):
     return importlib.import_module("3dfacerecon_amd." + n)
 
 
-def main():
-    B, S, K = 64, 200, 100
+def main(B=64):
+    S, K = 200, 100
     synth, netm, pipe, host = pkg("utils.synth"), pkg("nets.network"), pkg("pipeline"), pkg("_lib")
     dev = torch.device("cuda:0")
     A = synth.make_assets()
@@ -51,10 +51,15 @@ def main():
     for rnd in range(3):
         for lv in (1, 2, 3, 5, 6, 7, 0):
             res[names[lv]].append(wall(lv))
-    print(json.dumps(res, indent=1))
-    os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(res, open("gpurun_out/emit_ablate.json", "w"), indent=1)
+    return res
 
 
 if __name__ == "__main__":
-    main()
+    # emit_ablate.py [B ...]: one table per batch size (default 64); several sizes itemise the kernel's FIXED term
+    sizes = [int(x) for x in sys.argv[1:]] or [64]
+    out = {("%d faces" % b): main(b) for b in sizes}
+    if len(sizes) == 1:
+        out = out["%d faces" % sizes[0]]
+    print(json.dumps(out, indent=1))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open("gpurun_out/emit_ablate.json", "w"), indent=1)

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Profile session of a round (run on the GPU box: gpurun -- 'bash tools/gpu_run_final.sh'): parity suite, smoke, bench (default
-# flags, the driver's K = 20, the pipelined route, hipGraph replay, Q30), rocprofv3 kernel stats and PMC passes of the same
+# flags, the driver's K = 20, hipGraph replay, Q30), rocprofv3 kernel stats and PMC passes of the same
 # bench command, the PMC calibration kernels, the decode / emit probes, the decode backward under rocprofv3, caller configs
 # 3-5 with kernel stats.  Everything lands under gpurun_out/$O; tools/collect_profiles.py copies the summaries to profiles/.
 # Every leg's exit status is recorded in $O/legs.log; the script exits non-zero when any leg failed.
 export TMPDIR=/tmp
-O=gpurun_out/${1:-r5final}
+O=gpurun_out/${1:-r6final}
 mkdir -p $O
 : > $O/legs.log
 FAIL=0
@@ -26,7 +26,6 @@ leg smoke bash -c "python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke
 leg bench bash -c "python bench.py > $O/bench.json 2> $O/bench.err"
 leg bench_k20 bash -c "python bench.py --steps 20 --warmup 5 --cpu-faces 0 > $O/bench_k20.json 2>> $O/bench.err"
 leg bench_serial bash -c "python bench.py --route serial --cpu-faces 0 --no-ops-surface > $O/bench_serial.json 2>> $O/bench.err"
-leg bench_pipelined bash -c "python bench.py --route pipelined --cpu-faces 0 --no-ops-surface > $O/bench_pipelined.json 2>> $O/bench.err"
 leg bench_graph bash -c "python bench.py --graph --cpu-faces 0 --no-ops-surface > $O/bench_graph.json 2>> $O/bench.err"
 leg bench_q30 bash -c "FR_DECODE_ARITH=q30 python bench.py --cpu-faces 0 --no-ops-surface > $O/bench_q30.json 2>> $O/bench.err"
 leg bench_q30l5 bash -c "FR_DECODE_ARITH=q30l5 python bench.py --cpu-faces 0 --no-ops-surface > $O/bench_q30l5.json 2>> $O/bench.err"
@@ -36,16 +35,15 @@ leg phase_test bash -c "python examples/coarse_loop.py --phase test --batch 32 -
 # ---- rocprofv3: kernel stats + PMC passes of the same command (never --pmc together with a trace domain other than kernel-trace) --
 # (BCMD = the serial route: one batch in flight, the state the line's per-kernel figures and roofline object are measured in;
 #  prof_inflight = the default command, where kernels of two batches share the chip and a kernel's duration measures the sharing)
-BCMD="python3 bench.py --route serial --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0"
+BCMD="python3 bench.py --route serial --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0 --no-rccl-selftest --q30-levels 0"
 leg prof_bench bash -c "rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- $BCMD > $O/prof_bench.log 2>&1"
-leg prof_inflight bash -c "rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_inflight -- python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0 --no-serial-leg > $O/prof_inflight.log 2>&1"
+leg prof_inflight bash -c "rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_inflight -- python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0 --no-serial-leg --no-rccl-selftest --q30-levels 0 > $O/prof_inflight.log 2>&1"
 leg prof_q30l4 bash -c "FR_DECODE_ARITH=q30l4 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_q30l4 -- $BCMD > $O/prof_q30l4.log 2>&1"
 leg pmc_fetch_q30l4 bash -c "FR_DECODE_ARITH=q30l4 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch_q30l4 -- $BCMD > $O/pmc_fetch_q30l4.log 2>&1"
 leg pmc_write_q30l4 bash -c "FR_DECODE_ARITH=q30l4 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_write_q30l4 -- $BCMD > $O/pmc_write_q30l4.log 2>&1"
 leg pmc_sq_q30l4 bash -c "FR_DECODE_ARITH=q30l4 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_ANY -d $O/pmc_sq_q30l4 -- $BCMD > $O/pmc_sq_q30l4.log 2>&1"
 leg pmc_summary_q30l4 bash -c "python tools/pmc_summary.py $O/pmc_summary_q30l4.json $O/pmc_fetch_q30l4 $O/pmc_write_q30l4 $O/pmc_sq_q30l4 > /dev/null 2>> $O/bench.err"
-leg trace_inflight bash -c "rocprofv3 --kernel-trace --output-format csv -d $O/trace_inflight -- python3 bench.py --steps 100 --warmup 10 --repeats 3 --cpu-faces 0 --no-ops-surface --parity-faces 0 --no-serial-leg --q30-levels 0 > $O/trace_inflight.log 2>&1; python tools/inflight_trace.py $O/trace_inflight $O/inflight_timeline.json > /dev/null"
-leg prof_pipelined bash -c "rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pipelined -- python3 bench.py --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0 --route pipelined --no-serial-leg > $O/prof_pipelined.log 2>&1"
+leg trace_inflight bash -c "rocprofv3 --kernel-trace --output-format csv -d $O/trace_inflight -- python3 bench.py --steps 100 --warmup 10 --repeats 3 --cpu-faces 0 --no-ops-surface --parity-faces 0 --no-serial-leg --q30-levels 0 --no-rccl-selftest > $O/trace_inflight.log 2>&1; python tools/inflight_trace.py $O/trace_inflight $O/inflight_timeline.json > /dev/null"
 leg pmc_fetch bash -c "rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -- $BCMD > $O/pmc_fetch.log 2>&1"
 leg pmc_write bash -c "rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_write -- $BCMD > $O/pmc_write.log 2>&1"
 leg pmc_sq1 bash -c "rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_sq1 -- $BCMD > $O/pmc_sq1.log 2>&1"
@@ -75,7 +73,7 @@ find $O -name "*.db" -delete
 cat $O/legs.log
 tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; python -c "
 import json
-for f in ('bench','bench_again','bench_k20','bench_serial','bench_pipelined','bench_graph','bench_q30','bench_q30l5','bench_q30l4'):
+for f in ('bench','bench_again','bench_k20','bench_serial','bench_graph','bench_q30','bench_q30l5','bench_q30l4'):
     try:
         d=json.loads(open('$O/%s.json'%f).read().strip().splitlines()[-1]); print(f, round(d['value']), d['ms_per_step'], d.get('value_min'), d.get('value_max'), {k:round(v['avg_ms']*1e3,1) for k,v in d['kernels'].items()}, d.get('graph_replay_faces_per_s'), d.get('ops_surface_faces_per_s'), d.get('serial_plan_faces_per_s'), (d.get('parity') or {}).get('ok'))
     except Exception as e: print(f, 'ERR', e)
