@@ -34,7 +34,7 @@ def kernel_stats(name, out):
                                  for r in hot}}
 
 
-for j in ("bench", "bench_again", "bench_k20", "bench_serial", "bench_graph", "bench_q30", "bench_q30l5", "bench_q30l4",
+for j in ("bench", "bench_again", "bench_k20", "bench_serial", "bench_rows10", "bench_graph", "bench_q30", "bench_q30l5", "bench_q30l4",
           "phase_test", "inflight_timeline", "pmc_summary_q30l4"):
     f = os.path.join(src, j + ".json")
     if os.path.exists(f):
@@ -91,24 +91,13 @@ if os.path.exists(f):
     # shape tried.  KiB * 1024, per launch.
     def traffic(v, fetch_factor):
         return (fetch_factor * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
-    # vector-pipe time per SIMD and launch: the f32-input MFMA runs on the vector ALUs (it serialises with every other vector
-    # instruction of its SIMD: profiles/round4_probes/r4t), so a kernel's claim on that pipe is its MFMA busy cycles plus four
-    # cycles per other (wave64) vector instruction.  SQ_VALU_MFMA_BUSY_CYCLES = 32 x MFMA instructions; SQ_INSTS_VALU counts them too.
-    def vector_pipe(v):
-        mf = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
-        other = max(v.get("SQ_INSTS_VALU", 0.0) - mf / 32.0, 0.0)
-        return {"mfma_busy_cycles_per_simd": mf / 1024.0, "other_valu_cycles_per_simd": 4.0 * other / 1024.0,
-                "cycles_per_simd": (mf + 4.0 * other) / 1024.0}
-    vp = {"decode": vector_pipe(dec), "raster_emit": vector_pipe(emit), "resolve_write": vector_pipe(res)}
-    vp["step_cycles_per_simd"] = sum(x["cycles_per_simd"] for x in vp.values())
-    vp["step_us_at_2.1GHz"] = vp["step_cycles_per_simd"] / 2100.0
-    vp["note"] = ("1,024 SIMDs; four cycles per wave64 vector instruction, 32 per v_mfma_f32_16x16x4_f32; the decode holds 2.10-2.14 GHz, "
-                  "the render kernels a little more: the floor the vector pipe alone sets for one 64-face step")
     json.dump({
-        "vector_pipe": vp,
         "source": "rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- "
-                  "python3 bench.py --route serial --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0, MI355X, "
-                  "%s kernels (profiles/%s_pmc.json); per launch" % (tag, tag),
+                  "python3 bench.py --route serial --steps 10 --warmup 3 --repeats 2 --cpu-faces 0 --no-ops-surface --parity-faces 0 "
+                  "--no-rccl-selftest --q30-levels 0, MI355X, %s kernels (profiles/%s_pmc.json); per launch.  bench.py copies these figures "
+                  "into its line (`traffic`, `rocprofv3_avg_ms`): they are NOT measured by the run that prints the line" % (tag, tag),
+        "source_file": "profiles/pmc_traffic.json <- profiles/%s_pmc.json" % tag,
+        "kernel_stats_csv": "profiles/%s_kernel_stats.csv" % tag,
         "correction": "FETCH_SIZE x2 for the decode (16 B/lane streams are tallied at half), x1 for emit / resolve (gathers are "
                       "tallied in full); WRITE_SIZE exact -- calibrated in profiles/%s_pmc_calibration.json" % tag,
         "calibration": None if cal is None else {k: {"fetch_over_known": cal[k]["fetch_over_known"], "write_over_known": cal[k]["write_over_known"]}
@@ -123,7 +112,7 @@ if os.path.exists(f):
                               "rocprofv3_avg_ms": avg.get("resolve_write")},
         },
     }, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
-for extra in ("kernel_timing.log", "decode_breakdown.json", "emit_phase_account.json", "emit_ablate.json", "bwd_probe.log", "legs.log"):
+for extra in ("kernel_timing.log", "decode_breakdown.json", "emit_phase_account.json", "emit_ablate.json", "emit_fixed_term.json", "decode_stamps_by_xcd.json", "bwd_probe.log", "legs.log", "pytest_gpu.log"):
     f = os.path.join(src, extra)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s" % (tag, extra)))

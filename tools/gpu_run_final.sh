@@ -32,6 +32,7 @@ leg bench_q30l5 bash -c "FR_DECODE_ARITH=q30l5 python bench.py --cpu-faces 0 --n
 leg bench_q30l4 bash -c "FR_DECODE_ARITH=q30l4 python bench.py --cpu-faces 0 --no-ops-surface > $O/bench_q30l4.json 2>> $O/bench.err"
 leg bench_again bash -c "python bench.py --cpu-faces 0 > $O/bench_again.json 2>> $O/bench.err"
 leg phase_test bash -c "python examples/coarse_loop.py --phase test --batch 32 --steps 6 --warmup 2 > $O/phase_test.json 2> $O/phase_test.err"
+leg bench_rows10 bash -c "python bench.py --strip-rows 0 --cpu-faces 0 --no-ops-surface > $O/bench_rows10.json 2>> $O/bench.err"
 # ---- rocprofv3: kernel stats + PMC passes of the same command (never --pmc together with a trace domain other than kernel-trace) --
 # (BCMD = the serial route: one batch in flight, the state the line's per-kernel figures and roofline object are measured in;
 #  prof_inflight = the default command, where kernels of two batches share the chip and a kernel's duration measures the sharing)
@@ -56,7 +57,9 @@ leg calib bash -c "./tools/pmc_calib > $O/calib_bytes.json && rocprofv3 --kernel
 leg kernel_timing bash -c "python tools/kernel_timing.py > $O/kernel_timing.log 2>&1"
 leg decode_breakdown bash -c "./tools/decode_probe 64 53215 1 0 1 > $O/decode_breakdown.json 2> $O/decode_breakdown.err"
 leg emit_account bash -c "python tools/emit_probe.py > $O/emit_phase_account.json 2> $O/emit_probe.err"
-leg emit_ablate bash -c "python tools/emit_ablate.py > $O/emit_ablate.json 2> $O/emit_ablate.err"
+leg emit_ablate bash -c "python tools/emit_ablate.py 16 64 > $O/emit_ablate.json 2> $O/emit_ablate.err"
+leg emit_fixed bash -c "rocprofv3 --kernel-trace --output-format csv -d $O/emit_fixed -- python3 tools/emit_fixed_term.py > $O/emit_fixed.log 2>&1 && python3 tools/emit_fixed_term_report.py $O/emit_fixed $O/emit_fixed_term.json > /dev/null"
+leg decode_xcd bash -c "./tools/decode_probe 64 53215 1 2 1 > $O/decode_stamps_by_xcd.json 2> $O/decode_stamps_by_xcd.err"
 leg prof_bwd bash -c "BWD_B=64 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bwd -- python3 tools/decode_bwd_probe.py > $O/bwd_probe.log 2>&1"
 leg bwd_probe bash -c "python tools/decode_bwd_probe.py >> $O/bwd_probe.log 2>&1"
 leg bwd_ab bash -c "python tools/bwd_ab_probe.py > $O/bwd_ab.log 2>&1"
@@ -73,7 +76,7 @@ find $O -name "*.db" -delete
 cat $O/legs.log
 tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; python -c "
 import json
-for f in ('bench','bench_again','bench_k20','bench_serial','bench_graph','bench_q30','bench_q30l5','bench_q30l4'):
+for f in ('bench','bench_again','bench_k20','bench_rows10','bench_serial','bench_graph','bench_q30','bench_q30l5','bench_q30l4'):
     try:
         d=json.loads(open('$O/%s.json'%f).read().strip().splitlines()[-1]); print(f, round(d['value']), d['ms_per_step'], d.get('value_min'), d.get('value_max'), {k:round(v['avg_ms']*1e3,1) for k,v in d['kernels'].items()}, d.get('graph_replay_faces_per_s'), d.get('ops_surface_faces_per_s'), d.get('serial_plan_faces_per_s'), (d.get('parity') or {}).get('ok'))
     except Exception as e: print(f, 'ERR', e)
