@@ -2,9 +2,9 @@
 # Development record: the bench line at batch sizes either side of the configuration the metric is quoted on (64 faces).
 # usage (GPU box): tools/batch_sweep.sh [outdir]
 set -o pipefail
-OUT=${1:-gpurun_out/r5sweep}
+OUT=${1:-gpurun_out/r6sweep}
 mkdir -p "$OUT"
-for B in 16 32 64 128 256; do
+for B in 16 32 48 64 128 256; do
   timeout 300 python3 bench.py --batch $B --steps 50 --warmup 10 --cpu-faces 0 --no-ops-surface --no-rccl-selftest \
       > "$OUT/b$B.json" 2> "$OUT/b$B.err" || echo "batch $B: rc $?" >> "$OUT/failures.txt"
 done
@@ -12,7 +12,7 @@ python3 - "$OUT" <<'PY'
 import json, sys, os
 out = sys.argv[1]
 rows = []
-for B in (16, 32, 64, 128, 256):
+for B in (16, 32, 48, 64, 128, 256):
     p = os.path.join(out, "b%d.json" % B)
     try:
         d = json.loads(open(p).read().strip().splitlines()[-1])
