@@ -179,6 +179,8 @@ def _bind(L):
     L.fr_decode_3dmm_backward_packed_mu.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp,
                                                     ctypes.c_size_t, _vp]
     L.fr_decode_3dmm_backward_packed_mu.restype = _i
+    L.fr_render_depth_strip_rows.argtypes = [_i] * 4
+    L.fr_render_depth_strip_rows.restype = _i
     L.fr_debug_render_geom.argtypes = [_i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int)]
     L.fr_debug_render_geom.restype = None
     L.fr_debug_div3_sweep.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]
@@ -197,7 +199,8 @@ EXPORTS = ["fr_version", "fr_strerror", "fr_render_depth_workspace_bytes", "fr_r
            "fr_decode_3dmm_q30_lv", "fr_decode_render_forward_q30",
            "fr_decode_render_vertex_pitch", "fr_decode_render_vertex_bytes", "fr_decode_render_forward",
            "fr_decode_backward_basis_bytes", "fr_decode_backward_pack_basis", "fr_decode_3dmm_backward_packed",
-           "fr_debug_clock_probe", "fr_rendering_layer_forward_phases", "fr_decode_3dmm_backward_packed_mu"]
+           "fr_debug_clock_probe", "fr_rendering_layer_forward_phases", "fr_decode_3dmm_backward_packed_mu",
+           "fr_render_depth_strip_rows"]
 
 
 def lib():

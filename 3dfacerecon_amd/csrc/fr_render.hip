@@ -1630,6 +1630,12 @@ extern "C" void fr_debug_render_geom(int B, int ntri, int H, int W, int rows_ove
     out[0] = g.rows; out[1] = g.strips; out[2] = g.nseg; out[3] = g.binned_ok ? 1 : 0;
 }
 
+extern "C" int fr_render_depth_strip_rows(int B, int ntri, int H, int W) {
+    if (B <= 0 || ntri <= 0 || H <= 0 || W <= 0) return 0;
+    const RenderGeom g = render_geom(B, ntri, H, W, 0);   // (the library's own choice: no FR_RENDER_ROWS override)
+    return g.binned_ok ? g.rows : 0;
+}
+
 size_t fr_render_workspace_bytes_impl(int B, int ntri, int H, int W) {
     if ((size_t)B * H * W == 0 || ntri == 0) return 0;
     RenderGeom g = render_geom(B, ntri, H, W);

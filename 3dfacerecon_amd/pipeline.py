@@ -254,17 +254,18 @@ class BatchesInFlight:
 
     @staticmethod
     def strip_rows_in_flight(net, batch, height=None, width=None):
-        """The resolver's strip height for plans that run BESIDE another batch: four fifths of the library's own choice where that
-        is ten rows or more (200 x 200 at 64 faces: 8 instead of 10 -- 1,600 resolver workgroups instead of 1,280 fill the other
-        batch's gaps better: -0.9 us per batch with two in flight, +1.3 us one batch at a time, profiles/round4_probes/r4q,
-        round6_probes/r6e), otherwise 0 = no hint.  A scheduling hint: no result bit depends on it."""
+        """The resolver's strip height for plans that run BESIDE another batch: four fifths of the library's own choice in the regime
+        it was measured in -- strips of ten rows or more and at least four resolver workgroups per CU (200 x 200 at 64 faces: 8
+        rows instead of 10, 1,600 workgroups instead of 1,280, which fill the other batch's gaps better: -0.8 us per batch with two in
+        flight, +1.3 us one batch at a time; profiles/round4_probes/r4q, round6_probes/r6f) -- otherwise 0 = no hint.  A scheduling
+        hint: no result bit depends on it."""
         h = _host()
         H = int(net.im_size if height is None else height)
         W = int(net.im_size if width is None else width)
-        geom = (ctypes.c_int * 4)()
-        h.lib().fr_debug_render_geom(int(batch), int(net.tri.shape[1]), H, W, 0, geom)
-        rows = int(geom[0])
-        return (4 * rows) // 5 if rows >= 10 else 0
+        rows = int(h.lib().fr_render_depth_strip_rows(int(batch), int(net.tri.shape[1]), H, W))
+        if rows < 10 or int(batch) * ((H + rows - 1) // rows) < 1024:
+            return 0
+        return (4 * rows) // 5
 
     def submit(self, params=None, marks=None):
         """Launches decode + render of one batch on the next slot's stream; returns the slot (a DecodeRenderPlan).

@@ -182,6 +182,9 @@ int fr_decode_3dmm(const float* params, const void* packed_basis, const float* R
  *   batch: smaller resolver workgroups fill the other batch's gaps; +1.3 us one at a time).  A hint the binned rasteriser does not
  *   serve is ignored. */
 #define FR_PHASES_STRIP_ROWS(n) (((n) & 0xFF) << 8)
+/* The strip height the library itself picks for a shape (what FR_PHASES_STRIP_ROWS(0) means; no GPU needed), 0 when the binned
+ * rasteriser does not serve the shape: what a caller scales its hint from. */
+int fr_render_depth_strip_rows(int B, int ntri, int H, int W);
 int fr_decode_render_vertex_pitch(int N);
 size_t fr_decode_render_vertex_bytes(int B, int N);
 int fr_decode_render_forward(const float* params, const void* packed_basis, const float* R_override, const float* tri,

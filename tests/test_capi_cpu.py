@@ -74,6 +74,8 @@ def test_round3_entry_points_validate_before_any_hip_call():
     args = lambda phases, hand=one, hbytes=3 * 32 * 4, B=1: (one, one, nul, one, one, B, 20, 2, 2, 5, 8, 8, 1, f, hand, hbytes,  # noqa: E731
                                                              one, one, one, one, nul, 0, nul, phases)
     assert L.fr_decode_render_forward(*args(0)) == -1 and L.fr_decode_render_forward(*args(16)) == -1      # phase bits
+    assert L.fr_render_depth_strip_rows(64, 105840, 200, 200) == 10 and L.fr_render_depth_strip_rows(0, 5, 8, 8) == 0
+    assert L.fr_render_depth_strip_rows(32, 105840, 200, 200) == 7 and L.fr_render_depth_strip_rows(16, 105840, 448, 448) == 14
     # round 6: bits 8-15 carry the strip-height hint (FR_PHASES_STRIP_ROWS); a hint without a phase, or any bit beyond, is refused
     assert L.fr_decode_render_forward(*args(8 << 8)) == -1 and L.fr_decode_render_forward(*args(11 | 0x10000)) == -1
     assert L.fr_decode_render_forward(*args(11 | (8 << 8), B=0)) == 0 and L.fr_decode_render_forward(*args(11 | (8 << 8), hand=nul)) == -2
