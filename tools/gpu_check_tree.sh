@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-6 session 9 (GPU box): the committed tree -- whole GPU suite, smoke, the bench line with the driver's flags and the default ones.
+# (GPU box) The committed tree -- whole GPU suite, smoke, the bench line with the driver's flags and the default ones.
 export TMPDIR=/tmp
-O=gpurun_out/${1:-r6i}
+O=gpurun_out/${1:-check}
 mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -12 > $O/pytest_gpu.log
 echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
