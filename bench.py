@@ -708,6 +708,18 @@ def main():
             "parity": parity,
             "dist": dict(dist_info, per_rank_ms_per_step=per_rank_ms, launcher_world_size=world),
         }
+        # BASELINE.json configs[2..4] (the caller loops around this path): NOT run here -- `bench.py --config 3|4|5` runs them -- but the
+        # round's recorded lines ride along inside `config`, marked as what they are
+        try:
+            cc = json.load(open(os.path.join(ROOT, "profiles", "round6_caller_configs.json")))
+            out["config"]["caller_configs_recorded"] = {
+                "source": "profiles/round6_caller_configs.json (bench.py --config 3|4|5 on one MI355X = the per-GPU shard of configs 4-5; "
+                          "recorded in the round's profile session, not measured by this run)",
+                **{k: {"faces_per_s_per_gpu": v["line"]["value"], "ms_per_step": v["line"]["ms_per_step"], "faces_per_gpu": v["line"]["faces_per_gpu"],
+                       "hot_path_share_of_gpu_time": v.get("rocprofv3_kernel_stats", {}).get("hot_path_share")}
+                   for k, v in cc.items() if "line" in v}}
+        except (OSError, ValueError, KeyError):
+            pass
         if ops_elapsed is not None:
             out["ops_surface_faces_per_s"] = faces_per_step * K / ops_elapsed
             out["ops_surface"] = {"ms_per_step": 1e3 * ops_elapsed / K, "vs_plan": elapsed / ops_elapsed,

@@ -61,6 +61,8 @@ def test_bench_line_one_gpu():
     for k in ("after_timed_blocks", "after_serial_leg"):
         assert 1.0 < d["clock_GHz_held"][k]["median"] < 2.6
     assert "vector_pipe" not in d and "pipeline_hbm" not in d and "north_star_40pct_of_8TBs" not in d
+    rec = d["config"]["caller_configs_recorded"]     # configs 3-5 ride along as RECORDED lines, marked as such
+    assert "not measured by this run" in rec["source"] and rec["config3_fwd"]["faces_per_gpu"] == 32 and rec["config4_train_shard"]["ms_per_step"] > 100
     _check_roofline_is_self_contained(d)
     q = d["q30_inflight"]
     assert q["parity"]["ok"] and q["parity"]["mismatching_planes"] == 0 and q["parity"]["faces_checked"] == 16
