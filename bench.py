@@ -368,7 +368,9 @@ def main():
     # Per-kernel durations are taken live, inside the timed regions, with HIP events on the launch stream -- on every
     # EV_EVERY-th step only: an event pair costs a few microseconds of stream bubble, which at ~110 us per step would
     # otherwise tax every step by ~7 %.
-    EV_EVERY, EV_FIRST = 10, 5   # steps 5, 15, 25, ...: never the block's first step (it starts on an idle chip)
+    # (round 6, r6k: with the driver's K = 20 two bracketed steps per block cost the serial leg 0.5-1 us per step against one, and
+    # four cost the in-flight route 0.6: one bracketed step per twenty -- 80 samples per kernel at K = 20, R = 80)
+    EV_EVERY, EV_FIRST = 20, 5   # steps 5, 25, 45, ...: never the block's first step (it starts on an idle chip)
 
     def timed_blocks(pl, with_events):
         is_fl = hasattr(pl, "slots")
